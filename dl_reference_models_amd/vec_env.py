@@ -1,0 +1,271 @@
+"""Batched tensor API over the HIP step engine: B independent ``ReferenceModel`` envs on one GPU.
+
+``VecReferenceModel(env_config)`` takes the reference's ``env_config`` keys with the reference's
+defaults (MA-env = reference src/environments/reference_model_multi_agent.py:38-61) plus these
+extension keys:
+
+    num_envs        B (default 1)
+    device          torch device (default "cuda:0")
+    grid            uint8 [H,W] (shared by every env) or [B,H,W]; default: named grid ``env_name``
+    seeds           one NumPy seed per env; default ``seed + b`` when ``seed`` is given, else OS entropy
+    rng_words       uint64 [B,6] explicit PCG64 states (overrides seeds)
+    fixed_starts / fixed_goals   int16 [B,N,2] or [N,2] for ``deterministic`` on synthetic grids
+    lanes_per_env   engine tuning knob (0 = auto)
+
+All hot-path calls are asynchronous on the current torch stream; outputs are preallocated device
+tensors that are overwritten by the next call (clone them to keep them).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import get_grid as grid_tables
+
+INFO_ALL_KEYS = (
+    "goals_reached_step", "goals_reached_total", "blocking_count_step", "blocking_count_total",
+    "deadlock_step", "livelock_step", "deadlock_event_step", "livelock_event_step",
+    "deadlock_events_total", "livelock_events_total", "deadlock_steps_total", "livelock_steps_total",
+    "completion_ratio", "throughput",
+)
+
+
+def pcg64_words(seed) -> np.ndarray:
+    """uint64[6] PCG64 state of ``np.random.default_rng(seed)`` (SeedSequence expansion stays in NumPy)."""
+    st = np.random.default_rng(seed).bit_generator.state
+    s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, inc >> 64, inc & m, int(st["has_uint32"]), int(st["uinteger"])], dtype=np.uint64)
+
+
+def config_flags(cfg: dict) -> int:
+    f = 0
+    if cfg.get("normalize_goal_delta", True):
+        f |= L.FLAG_NORMALIZE_GOAL_DELTA
+    if cfg.get("include_goal_distance", False):
+        f |= L.FLAG_GOAL_DISTANCE
+    if bool(cfg.get("include_action_mask_in_obs", False)):
+        f |= L.FLAG_ACTION_MASK
+    if bool(cfg.get("include_blocking_pressure_in_obs", True)):
+        f |= L.FLAG_BLOCKING_PRESSURE
+    if bool(cfg.get("lifelong_mapf", False)):
+        f |= L.FLAG_LIFELONG
+    if bool(cfg.get("enable_lock_metrics", True)):
+        f |= L.FLAG_LOCK_METRICS
+    if cfg.get("deterministic", False):
+        f |= L.FLAG_DETERMINISTIC
+    return f
+
+
+class VecReferenceModel:
+    def __init__(self, env_config: dict):
+        cfg = dict(env_config)
+        self.env_config = cfg
+        self._lib = L.load()  # raises if the HIP library is not built: no CPU fallback
+        self.device = torch.device(cfg.get("device", "cuda:0"))
+        if self.device.type != "cuda":
+            raise ValueError("VecReferenceModel runs on a HIP device only (device='cuda:N')")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.num_envs = B = int(cfg.get("num_envs", 1))
+        self.num_agents = N = int(cfg.get("num_agents", 2))
+        self.sensor_range = int(cfg.get("sensor_range", 1))
+        self.steps_per_episode = int(cfg.get("steps_per_episode", 100))
+        self.lifelong_mapf = bool(cfg.get("lifelong_mapf", False))
+        self.deterministic = bool(cfg.get("deterministic", False))
+        self.info_mode = str(cfg.get("info_mode", "lite")).lower()
+        if self.info_mode not in {"lite", "full"}:
+            raise ValueError(f"Unsupported info_mode '{self.info_mode}'. Expected 'lite' or 'full'.")
+
+        grid = cfg.get("grid", None)
+        if grid is None:
+            grid = grid_tables.get_grid(cfg["env_name"])
+        grid = np.ascontiguousarray(grid, dtype=np.uint8)
+        if grid.ndim == 2:
+            shared, self.grids = 1, grid[None]
+        elif grid.ndim == 3 and grid.shape[0] == B:
+            shared, self.grids = 0, grid
+        else:
+            raise ValueError("grid must be [H,W] or [num_envs,H,W]")
+        H, W = int(self.grids.shape[1]), int(self.grids.shape[2])
+        self.grid_shape = (H, W)
+
+        c = L.MapfConfig(
+            B, H, W, N, self.sensor_range, self.steps_per_episode, config_flags(cfg),
+            int(cfg.get("deadlock_window_steps", 8)), int(cfg.get("livelock_window_steps", 16)),
+            int(cfg.get("lock_nearby_manhattan", 2)), int(cfg.get("lock_min_neighbors", 1)),
+            float(cfg.get("lock_progress_epsilon", 1)), int(self.device.index), int(cfg.get("lanes_per_env", 0)),
+        )
+        self._cfg = c
+        self.obs_len = int(self._lib.mapf_obs_len(C.byref(c)))
+        self.livelock_window = max(1, int(cfg.get("livelock_window_steps", 16)))
+        h = C.c_void_p()
+        rc = self._lib.mapf_create(C.byref(c), C.byref(h))
+        if rc != L.MAPF_OK:
+            raise ValueError(f"mapf_create failed ({rc}): {self._lib.mapf_last_error(None).decode()}")
+        self._h = h
+        self._check(self._lib.mapf_set_grids(h, self.grids.ctypes.data_as(C.c_void_p), shared), ValueError)
+
+        # RNG: one NumPy PCG64 stream per env (MA-env:74-78)
+        if cfg.get("rng_words", None) is not None:
+            words = np.ascontiguousarray(cfg["rng_words"], dtype=np.uint64).reshape(B, 6)
+        else:
+            seeds = cfg.get("seeds", None)
+            if seeds is None:
+                seed = cfg.get("seed", None)
+                seeds = [None] * B if seed is None else [int(seed) + b for b in range(B)]
+            if len(seeds) != B:
+                raise ValueError("need one seed per env")
+            words = np.stack([pcg64_words(s) for s in seeds])
+        self._check(self._lib.mapf_set_rng_state(h, words.ctypes.data_as(C.c_void_p)))
+
+        with torch.cuda.device(self.device):
+            dev = self.device
+            Lo = self.obs_len
+            self._obs = torch.zeros((B, N, Lo), dtype=torch.float32, device=dev)
+            self._final_obs = torch.zeros((B, N, Lo), dtype=torch.float32, device=dev)
+            self._rewards = torch.zeros((B, N), dtype=torch.float32, device=dev)
+            self._terminated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self._truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self._info_all = torch.zeros((B, L.INFO_ALL), dtype=torch.float32, device=dev)
+            self._info_agent = torch.zeros((B, N, 2), dtype=torch.uint8, device=dev)
+
+        if self.deterministic:
+            # fixed start/goal tables (MA-env:124-132)
+            fs, fg = cfg.get("fixed_starts", None), cfg.get("fixed_goals", None)
+            if fs is None or fg is None:
+                s = grid_tables.get_start_positions(cfg["env_name"], N)
+                g = grid_tables.get_goal_positions(cfg["env_name"], N)
+                fs = np.array([s[f"agent_{i}"] for i in range(N)], dtype=np.int16)
+                fg = np.array([g[f"agent_{i}"] for i in range(N)], dtype=np.int16)
+            fs = np.ascontiguousarray(np.broadcast_to(np.asarray(fs, np.int16).reshape(-1, N, 2), (B, N, 2)))
+            fg = np.ascontiguousarray(np.broadcast_to(np.asarray(fg, np.int16).reshape(-1, N, 2), (B, N, 2)))
+            self._check(self._lib.mapf_set_fixed_starts_goals(
+                h, fs.ctypes.data_as(C.c_void_p), fg.ctypes.data_as(C.c_void_p)), ValueError)
+        else:
+            # the reference ctor draws one generate_starts_goals() (MA-env:133-134): same RNG consumption
+            self._check(self._lib.mapf_reset(h, None, None, self._stream()))
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc: int, exc=RuntimeError):
+        if rc != L.MAPF_OK:
+            raise exc(f"{self._lib.mapf_last_error(self._h).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mapf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def launch_info(self) -> dict:
+        b, t, l, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
+        return {"blocks": b.value, "threads": t.value, "lds_bytes": l.value, "lanes_per_env": p.value}
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self, env_mask: torch.Tensor | None = None) -> torch.Tensor:
+        """reset() of every env (or those with env_mask != 0).  Returns obs [B,N,L] (device)."""
+        mptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = C.c_void_p(env_mask.data_ptr())
+        self._check(self._lib.mapf_reset(self._h, mptr, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        return self._obs
+
+    def step(self, actions: torch.Tensor, auto_reset: bool = True, want_final_obs: bool = False) -> dict:
+        """One step of every env.  actions: int8 [B,N] on the env's device."""
+        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        if tuple(actions.shape) != (self.num_envs, self.num_agents):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.num_agents)}")
+        fo = C.c_void_p(self._final_obs.data_ptr()) if (want_final_obs and auto_reset) else None
+        self._check(self._lib.mapf_step(
+            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+            C.c_void_p(self._rewards.data_ptr()), C.c_void_p(self._terminated.data_ptr()),
+            C.c_void_p(self._truncated.data_ptr()), C.c_void_p(self._info_all.data_ptr()),
+            C.c_void_p(self._info_agent.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
+        return {
+            "obs": self._obs, "rewards": self._rewards, "terminated": self._terminated, "truncated": self._truncated,
+            "info_all": self._info_all, "info_agent": self._info_agent,
+            "final_obs": self._final_obs if fo is not None else None,
+        }
+
+    def step_raw(self, actions_ptr: int, stream_ptr: int, auto_reset: int = 1) -> int:
+        """Lowest-overhead launch for benchmarks: raw device pointer in, preallocated outputs."""
+        return self._lib.mapf_step(
+            self._h, actions_ptr, self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(),
+            self._truncated.data_ptr(), self._info_all.data_ptr(), self._info_agent.data_ptr(), None, auto_reset,
+            stream_ptr)
+
+    def poll_error(self):
+        """Synchronize and raise the Python exception the reference would have raised inside step()."""
+        env, agent, value = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        rc = self._lib.mapf_poll_error(self._h, self._stream(), C.byref(env), C.byref(agent), C.byref(value))
+        if rc == L.MAPF_OK:
+            return
+        if rc == L.MAPF_ERR_BAD_ACTION:
+            err = ValueError(f"Invalid action {value.value} for agent_{agent.value}")
+        elif rc == L.MAPF_ERR_NO_RESPAWN:
+            err = RuntimeError("No valid cell available for lifelong goal reassignment.")
+        else:
+            err = RuntimeError(self._lib.mapf_last_error(self._h).decode())
+        err.env_index = env.value
+        raise err
+
+    # ------------------------------------------------------------------------------------------
+    def get_state(self) -> dict:
+        B, N = self.num_envs, self.num_agents
+        out = {
+            "positions": np.zeros((B, N, 2), np.int16), "goals": np.zeros((B, N, 2), np.int16),
+            "starts": np.zeros((B, N, 2), np.int16), "reached": np.zeros((B, N), np.uint8),
+            "completed_once": np.zeros((B, N), np.uint8), "pressure_prev": np.zeros((B, N), np.uint8),
+            "counters": np.zeros((B, L.NUM_COUNTERS), np.int32), "rng_words": np.zeros((B, 6), np.uint64),
+            "lock_history": np.zeros((B, N, 3), np.uint64),
+            "distance_ring": np.zeros((B, self.livelock_window, N), np.int16),
+        }
+        s = L.MapfState(**{k: v.ctypes.data_as(C.c_void_p) for k, v in out.items()})
+        self._check(self._lib.mapf_get_state(self._h, C.byref(s)))
+        return out
+
+    def set_state(self, *, positions=None, goals=None, starts=None, reached=None, completed_once=None,
+                  pressure_prev=None, counters=None, rng_words=None, lock_history=None, distance_ring=None,
+                  clear_episode: bool = False):
+        """Overwrite parts of the env state (what the reference's tests do by poking private arrays).
+        clear_episode=True also zeroes flags, counters and lock tracking, like the tests' _set_state helpers."""
+        B, N = self.num_envs, self.num_agents
+        if clear_episode:
+            reached = np.zeros((B, N), np.uint8) if reached is None else reached
+            completed_once = np.zeros((B, N), np.uint8) if completed_once is None else completed_once
+            pressure_prev = np.zeros((B, N), np.uint8) if pressure_prev is None else pressure_prev
+            lock_history = np.zeros((B, N, 3), np.uint64) if lock_history is None else lock_history
+            if counters is None:
+                counters = self.get_state()["counters"]
+                counters[:, : L.CTR_EPISODES_DONE] = 0
+        keep = []
+
+        def ptr(a, dtype, shape):
+            if a is None:
+                return None
+            arr = np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(shape))
+            keep.append(arr)
+            return arr.ctypes.data_as(C.c_void_p)
+
+        s = L.MapfState(
+            ptr(positions, np.int16, (B, N, 2)), ptr(goals, np.int16, (B, N, 2)), ptr(starts, np.int16, (B, N, 2)),
+            ptr(reached, np.uint8, (B, N)), ptr(completed_once, np.uint8, (B, N)), ptr(pressure_prev, np.uint8, (B, N)),
+            ptr(counters, np.int32, (B, L.NUM_COUNTERS)), ptr(rng_words, np.uint64, (B, 6)),
+            ptr(lock_history, np.uint64, (B, N, 3)), ptr(distance_ring, np.int16, (B, self.livelock_window, N)),
+        )
+        self._check(self._lib.mapf_set_state(self._h, C.byref(s)), ValueError)

@@ -1,0 +1,185 @@
+/*
+ * mapf_step.h -- C ABI of libmapfstep.so, the MI355X (gfx950) vectorized step engine that replaces
+ * the hot path of the reference's multi-agent grid environment
+ * (/root/reference/src/environments/reference_model_multi_agent.py, "MA-env" below).
+ *
+ * One handle owns B independent env instances resident in HBM on one GPU.  Plain pointers and sizes
+ * only; no torch / C++ types cross this boundary.  A handle is NOT thread-safe (the reference env is
+ * single-threaded and not re-entrant either); use one handle per host thread / per GPU.
+ *
+ * Pointer convention
+ *   - "host"   : ordinary host memory, copied synchronously inside the call (setup / inspection calls)
+ *   - "device" : HIP device memory on the handle's GPU, caller-owned, used asynchronously on `stream`
+ *                (the hot-path calls mapf_reset / mapf_step).  `stream` is a hipStream_t passed as void*
+ *                (NULL = the default stream).
+ *
+ * Every function returns MAPF_OK (0) or a negative MAPF_ERR_* code; mapf_last_error() gives the text.
+ * Errors the reference raises as Python exceptions *inside* step() (bad action -> ValueError MA-env:504-506,
+ * no respawn cell -> RuntimeError MA-env:296-298) happen per env on the device; they are latched in a
+ * device-side error record that mapf_poll_error() reads back.
+ *
+ * Reference interface each entry point replaces (a maintainer binds these with ctypes):
+ *   mapf_create + mapf_set_grids + mapf_set_rng_state (+ mapf_set_fixed_starts_goals)
+ *                         <- ReferenceModel.__init__            MA-env:34-184 (config keys :38-61, state block :82-120,
+ *                                                               RNG :74-78, grid :80, fixed tables :124-132)
+ *   mapf_reset            <- ReferenceModel.reset               MA-env:440-472 (+ generate_starts_goals :267-282)
+ *   mapf_step             <- ReferenceModel.step                MA-env:474-695 (+ get_obs :707-747, get_action_mask :749-773,
+ *                                                               _flatten_observation :306-328, _assign_new_goal :284-304,
+ *                                                               lock detector :374-438)
+ *   mapf_get_state / mapf_set_state
+ *                         <- the private arrays callers and tests read or poke: _positions_arr, _goals_arr, _starts_arr,
+ *                            _reached_arr, _completed_once_arr, _blocking_pressure_prev_arr, step_count, _episode_* counters
+ *                            (MA-env:83-89, :63-69; read by src/trainers/callbacks.py:111-131,265-307 and main.py:265,314)
+ *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
+ */
+#ifndef MAPF_STEP_H
+#define MAPF_STEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPF_VERSION_MAJOR 0
+#define MAPF_VERSION_MINOR 1
+
+/* limits of this build (checked by mapf_create) */
+#define MAPF_MAX_DIM 64          /* grid height and width */
+#define MAPF_MAX_AGENTS 64       /* agents per env (one wavefront lane per agent) */
+#define MAPF_MAX_SENSOR_RANGE 5  /* view side 2*sr+1 <= 11 */
+#define MAPF_MAX_LOCK_WINDOW 64  /* deadlock / livelock window steps */
+
+/* config flags (defaults of the reference in brackets, MA-env:41-61) */
+#define MAPF_FLAG_NORMALIZE_GOAL_DELTA 1u /* normalize_goal_delta [on]  */
+#define MAPF_FLAG_GOAL_DISTANCE 2u        /* include_goal_distance [off] */
+#define MAPF_FLAG_ACTION_MASK 4u          /* include_action_mask_in_obs [off] */
+#define MAPF_FLAG_BLOCKING_PRESSURE 8u    /* include_blocking_pressure_in_obs [on] */
+#define MAPF_FLAG_LIFELONG 16u            /* lifelong_mapf [off] */
+#define MAPF_FLAG_LOCK_METRICS 32u        /* enable_lock_metrics [on] */
+#define MAPF_FLAG_DETERMINISTIC 64u       /* deterministic [off]: reset() re-places agents on fixed starts, no RNG */
+
+/* status codes */
+#define MAPF_OK 0
+#define MAPF_ERR_BAD_ACTION (-1)  /* reference: ValueError "Invalid action ..." MA-env:504-506 */
+#define MAPF_ERR_FEW_FREE (-2)    /* reference: ValueError, fewer than 2N free cells MA-env:270-275 */
+#define MAPF_ERR_NO_RESPAWN (-3)  /* reference: RuntimeError, no cell for lifelong goal MA-env:296-298 */
+#define MAPF_ERR_CONFIG (-4)      /* config outside this build's limits / inconsistent arguments */
+#define MAPF_ERR_HIP (-5)         /* a HIP runtime call failed */
+#define MAPF_ERR_STATE (-6)       /* call sequence error (e.g. step before grids were set) */
+
+/* info_all[...] column order: the reference's info["__all__"] keys MA-env:639-655 */
+#define MAPF_INFO_ALL 14
+#define MAPF_INFO_GOALS_REACHED_STEP 0
+#define MAPF_INFO_GOALS_REACHED_TOTAL 1
+#define MAPF_INFO_BLOCKING_COUNT_STEP 2
+#define MAPF_INFO_BLOCKING_COUNT_TOTAL 3
+#define MAPF_INFO_DEADLOCK_STEP 4
+#define MAPF_INFO_LIVELOCK_STEP 5
+#define MAPF_INFO_DEADLOCK_EVENT_STEP 6
+#define MAPF_INFO_LIVELOCK_EVENT_STEP 7
+#define MAPF_INFO_DEADLOCK_EVENTS_TOTAL 8
+#define MAPF_INFO_LIVELOCK_EVENTS_TOTAL 9
+#define MAPF_INFO_DEADLOCK_STEPS_TOTAL 10
+#define MAPF_INFO_LIVELOCK_STEPS_TOTAL 11
+#define MAPF_INFO_COMPLETION_RATIO 12 /* emitted by the reference only in lifelong mode; always computed here */
+#define MAPF_INFO_THROUGHPUT 13       /* idem */
+
+/* per-env counters of mapf_state.counters[B][MAPF_NUM_COUNTERS] */
+#define MAPF_NUM_COUNTERS 16
+#define MAPF_CTR_STEP_COUNT 0           /* step_count                         MA-env:37  */
+#define MAPF_CTR_HIST_ROWS 1            /* rows appended to the lock history since its reset (unsaturated) */
+#define MAPF_CTR_BLOCKING_COUNT 2       /* _episode_blocking_count            MA-env:63  */
+#define MAPF_CTR_GOALS_REACHED_TOTAL 3  /* _episode_goals_reached_total       MA-env:88  */
+#define MAPF_CTR_DEADLOCK_EVENTS 4      /* _episode_deadlock_events           MA-env:64  */
+#define MAPF_CTR_LIVELOCK_EVENTS 5
+#define MAPF_CTR_DEADLOCK_STEPS 6
+#define MAPF_CTR_LIVELOCK_STEPS 7
+#define MAPF_CTR_LOCK_STATE_PREV 8      /* bit0 _deadlock_state_prev, bit1 _livelock_state_prev MA-env:68-69 */
+#define MAPF_CTR_EPISODES_DONE 9        /* episodes finished by this env since create (auto-reset bookkeeping) */
+
+typedef struct mapf_config {
+    int32_t num_envs;           /* B >= 1 */
+    int32_t height, width;      /* grid shape, each <= MAPF_MAX_DIM */
+    int32_t num_agents;         /* N <= MAPF_MAX_AGENTS */
+    int32_t sensor_range;       /* MA-env:40 */
+    int32_t steps_per_episode;  /* MA-env:38 */
+    uint32_t flags;             /* MAPF_FLAG_* */
+    int32_t deadlock_window_steps; /* MA-env:56, clamped to >= 1 */
+    int32_t livelock_window_steps; /* MA-env:57 */
+    int32_t lock_nearby_manhattan; /* MA-env:58 */
+    int32_t lock_min_neighbors;    /* MA-env:60 */
+    double lock_progress_epsilon;  /* MA-env:59 */
+    int32_t device;             /* HIP device ordinal */
+    int32_t lanes_per_env;      /* 0 = auto (smallest power of two >= max(N,4)); else 4/8/16/32/64 */
+} mapf_config;
+
+typedef struct mapf_engine *mapf_handle;
+
+/* host views for mapf_get_state / mapf_set_state; NULL members are skipped */
+typedef struct mapf_state {
+    int16_t *positions;      /* [B][N][2] (row, col)  _positions_arr */
+    int16_t *goals;          /* [B][N][2]             _goals_arr */
+    int16_t *starts;         /* [B][N][2]             _starts_arr */
+    uint8_t *reached;        /* [B][N]                _reached_arr (sticky) */
+    uint8_t *completed_once; /* [B][N]                _completed_once_arr */
+    uint8_t *pressure_prev;  /* [B][N]  0/1           _blocking_pressure_prev_arr */
+    int32_t *counters;       /* [B][MAPF_NUM_COUNTERS] */
+    uint64_t *rng_words;     /* [B][6] numpy PCG64: state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger */
+    uint64_t *lock_history;  /* [B][N][3] shift registers, bit k = flag k steps ago: moved, failed_move, goal_progress */
+    int16_t *distance_ring;  /* [B][livelock_window][N], slot = history row index mod livelock_window */
+} mapf_state;
+
+uint32_t mapf_version(void);
+/* flat observation length L for a config (MA-env:214-236): V*V + 2 [+1] [+1] [+5] */
+int32_t mapf_obs_len(const mapf_config *cfg);
+
+int mapf_create(const mapf_config *cfg /* host */, mapf_handle *out);
+int mapf_destroy(mapf_handle h);
+const char *mapf_last_error(mapf_handle h); /* h may be NULL: error of the last failed mapf_create */
+
+/* grids: host uint8 [B][H][W] (shared == 0) or one [H][W] used by every env (shared != 0); 0 free, 1 obstacle.
+ * Fails with MAPF_ERR_FEW_FREE when an env has fewer than 2N free cells (reference ctor, MA-env:270-275). */
+int mapf_set_grids(mapf_handle h, const uint8_t *grids /* host */, int32_t shared);
+
+/* numpy Generator(PCG64) state per env, host uint64 [B][6] (see mapf_state.rng_words).  Seed expansion
+ * (SeedSequence) is the caller's job: np.random.default_rng(seed).bit_generator.state (MA-env:74-78). */
+int mapf_set_rng_state(mapf_handle h, const uint64_t *rng_words /* host */);
+
+/* deterministic mode (MA-env:124-132): fixed starts / goals, host int16 [B][N][2] each; also places agents. */
+int mapf_set_fixed_starts_goals(mapf_handle h, const int16_t *starts /* host */, const int16_t *goals /* host */);
+
+int mapf_get_state(mapf_handle h, mapf_state *out /* host views */);
+int mapf_set_state(mapf_handle h, const mapf_state *in /* host views */);
+
+/* reset (MA-env:440-472).  env_mask: device uint8 [B], nonzero = reset that env; NULL = all.
+ * obs: device float32 [B][N][L], rows of reset envs are written; may be NULL (state only -- the
+ * reference ctor's own generate_starts_goals() draw, MA-env:133-134, is mapf_reset with obs NULL). */
+int mapf_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *obs /* device */, void *stream);
+
+/* one step of every env (MA-env:474-695).  All pointers device; any output may be NULL.
+ *   actions     int8   [B][N]      0 NO_OP, 1 UP, 2 RIGHT, 3 DOWN, 4 LEFT (actions.py:1-5)
+ *   obs         float32[B][N][L]   per-agent flat observation, reference layout (MA-env:306-328)
+ *   rewards     float32[B][N]
+ *   terminated  uint8  [B]         terminated["__all__"]   (per-agent flags equal it, MA-env:668-690)
+ *   truncated   uint8  [B]         truncated["__all__"]
+ *   info_all    float32[B][14]     MAPF_INFO_* columns
+ *   info_agent  uint8  [B][N][2]   {blocking, goal_reached_step}  (MA-env:627-629)
+ *   final_obs   float32[B][N][L]   only with auto_reset: terminal observation of envs that finished
+ * auto_reset != 0: an env whose episode ended is reset() inside the same launch, exactly as the reference
+ * harness does right after the step (scripts/benchmark_multi_agent_env.py:89-95); its `obs` rows then hold
+ * the reset observation. */
+int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
+              float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream);
+
+/* read (and clear) the device error record; synchronizes `stream`.  Returns MAPF_OK when no env has
+ * failed, else the code of the first failure with its env / agent / offending value. */
+int mapf_poll_error(mapf_handle h, void *stream, int32_t *env, int32_t *agent, int32_t *value);
+
+/* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes) */
+int mapf_launch_info(mapf_handle h, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
