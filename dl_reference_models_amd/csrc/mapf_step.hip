@@ -520,6 +520,33 @@ __global__ __launch_bounds__(64) void k_reset(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// observe kernel: observation of every agent from the current (static) state, nothing is modified.
+// What the reference computes when get_obs / _flatten_observation are called outside step()
+// (its tests do: tests/test_reference_model_multi_agent_invariants.py:76-95).
+// ------------------------------------------------------------------------------------------------
+template <int LPE, bool WIDE>
+__global__ __launch_bounds__(64) void k_observe(const Params p) {
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t *lrows = reinterpret_cast<uint64_t *>(lds_raw);
+    float *stage = reinterpret_cast<float *>(lds_raw + p.lds_stage_off);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, p.B - env0);
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : p.B - 1;
+    const bool is_agent = env_ok && a < p.N;
+    load_rows_to_lds<LPE>(p, lrows, lane, env0, ngroups);
+    Lane st;
+    load_lane(p, env, a, is_agent, st);
+    __syncthreads();
+    observe<LPE, WIDE>(p, lrows + grp * p.H, stage + (size_t)(grp * p.N + a) * p.L, is_agent, a, st.pos | (st.pos << 16),
+                       st.goal, true, (st.flags & kFlagPressure) != 0);
+    __syncthreads();
+    flush_obs<LPE>(p, stage, lane, env0, ngroups, env_ok ? 0 : 2);
+}
+
+// ------------------------------------------------------------------------------------------------
 // step kernel
 // ------------------------------------------------------------------------------------------------
 template <int LPE, bool WIDE>
@@ -909,13 +936,26 @@ hipError_t launch_reset_t(const mapf_engine *e, const Params &p, hipStream_t s) 
     hipLaunchKernelGGL((k_reset<LPE, WIDE>), dim3(e->blocks), dim3(64), e->lds_bytes, s, p);
     return hipGetLastError();
 }
+template <int LPE, bool WIDE>
+hipError_t launch_observe_t(const mapf_engine *e, const Params &p, hipStream_t s) {
+    hipLaunchKernelGGL((k_observe<LPE, WIDE>), dim3(e->blocks), dim3(64), e->lds_bytes, s, p);
+    return hipGetLastError();
+}
 
-template <bool STEP>
-hipError_t dispatch(const mapf_engine *e, const Params &p, hipStream_t s) {
-#define MAPF_CASE(L)                                                                                   \
-    case L:                                                                                            \
-        if (e->wide) return STEP ? launch_step_t<L, true>(e, p, s) : launch_reset_t<L, true>(e, p, s);  \
-        return STEP ? launch_step_t<L, false>(e, p, s) : launch_reset_t<L, false>(e, p, s);
+enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
+
+template <int LPE, bool WIDE>
+hipError_t launch_kind(int kind, const mapf_engine *e, const Params &p, hipStream_t s) {
+    if (kind == KIND_STEP) return launch_step_t<LPE, WIDE>(e, p, s);
+    if (kind == KIND_RESET) return launch_reset_t<LPE, WIDE>(e, p, s);
+    return launch_observe_t<LPE, WIDE>(e, p, s);
+}
+
+hipError_t dispatch(int kind, const mapf_engine *e, const Params &p, hipStream_t s) {
+#define MAPF_CASE(L)                                              \
+    case L:                                                       \
+        if (e->wide) return launch_kind<L, true>(kind, e, p, s);  \
+        return launch_kind<L, false>(kind, e, p, s);
     switch (e->lpe) {
         MAPF_CASE(4)
         MAPF_CASE(8)
@@ -1214,7 +1254,7 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     p.env_mask = env_mask;
     p.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, dispatch<false>(e, p, (hipStream_t)stream));
+    HIP_TRY(e, dispatch(KIND_RESET, e, p, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -1232,7 +1272,18 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     p.info_agent = info_agent;
     p.final_obs = final_obs;
     p.auto_reset = auto_reset;
-    HIP_TRY(e, dispatch<true>(e, p, (hipStream_t)stream));
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, dispatch(KIND_STEP, e, p, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+int mapf_observe(mapf_handle e, float *obs, void *stream) {
+    if (!e || !obs) return fail(e, MAPF_ERR_CONFIG, "null argument");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_observe");
+    Params p = e->p;
+    p.obs = obs;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, dispatch(KIND_OBSERVE, e, p, (hipStream_t)stream));
     return MAPF_OK;
 }
 

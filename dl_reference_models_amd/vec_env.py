@@ -202,6 +202,12 @@ class VecReferenceModel:
             "final_obs": self._final_obs if fo is not None else None,
         }
 
+    def observe(self) -> torch.Tensor:
+        """Observation of every agent from the current state (no state change).  Returns a fresh tensor."""
+        out = torch.empty_like(self._obs)
+        self._check(self._lib.mapf_observe(self._h, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def step_raw(self, actions_ptr: int, stream_ptr: int, auto_reset: int = 1) -> int:
         """Lowest-overhead launch for benchmarks: raw device pointer in, preallocated outputs."""
         return self._lib.mapf_step(

@@ -1,0 +1,64 @@
+"""Synthetic workloads of BASELINE.json / SURVEY 8(d): build-defined random-obstacle grids (the
+reference ships only 8 named grids) and the env flags the headline metric is quoted on.
+
+Every quantity is a function of the GLOBAL env index, so a shard of envs is the same whichever
+rank / GPU count runs it.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+# common flags: sensor_range 2, mask + blocking pressure in obs (L = 33), lock metrics on
+COMMON = {
+    "env_name": "synthetic", "sensor_range": 2, "steps_per_episode": 100, "deterministic": False,
+    "normalize_goal_delta": True, "include_goal_distance": False, "include_blocking_pressure_in_obs": True,
+    "include_action_mask_in_obs": True, "enable_lock_metrics": True, "info_mode": "lite",
+}
+
+WORKLOADS = {
+    # name: (envs per GPU, H, W, agents, obstacle density, config overrides)
+    "c1_10x10_n2": (1, 10, 10, 2, 0.10, {"sensor_range": 1}),
+    "c2_1024x16x16_n4": (1024, 16, 16, 4, 0.20, {}),
+    "c3_8192x32x32_n8": (8192, 32, 32, 8, 0.40, {}),
+    "c5_1024x64x64_n64_lifelong": (1024, 64, 64, 64, 0.20, {"lifelong_mapf": True, "steps_per_episode": 256}),
+}
+HEADLINE = "c3_8192x32x32_n8"  # BASELINE.json metric: agent-steps/sec at 8192 envs x 8 agents on 32x32
+
+
+def synthetic_grid(env_id: int, h: int, w: int, density: float, n_agents: int) -> np.ndarray:
+    """grid = default_rng(10_000 + env_id).random((h, w)) < density; reseed (+100_000) while free cells < 2N."""
+    s = 10_000 + int(env_id)
+    while True:
+        g = (np.random.default_rng(s).random((h, w)) < density).astype(np.uint8)
+        if int((g == 0).sum()) >= 2 * n_agents:
+            return g
+        s += 100_000
+
+
+def synthetic_grids(env_ids, h, w, density, n_agents) -> np.ndarray:
+    return np.stack([synthetic_grid(i, h, w, density, n_agents) for i in env_ids])
+
+
+def workload_config(name: str, env_ids) -> dict:
+    """env_config for VecReferenceModel: grids + one NumPy seed per env (= its global env index)."""
+    _b, h, w, n, density, over = WORKLOADS[name]
+    cfg = dict(COMMON)
+    cfg.update(over)
+    cfg["num_agents"] = n
+    cfg["num_envs"] = len(env_ids)
+    cfg["grid"] = synthetic_grids(env_ids, h, w, density, n)
+    cfg["seeds"] = [int(i) for i in env_ids]
+    return cfg
+
+
+def obs_len(cfg: dict) -> int:
+    v = 2 * int(cfg.get("sensor_range", 1)) + 1
+    return (v * v + 2 + (1 if cfg.get("include_goal_distance", False) else 0)
+            + (1 if cfg.get("include_blocking_pressure_in_obs", True) else 0)
+            + (5 if cfg.get("include_action_mask_in_obs", False) else 0))
+
+
+def algorithmic_bytes_per_env_step(n_agents: int, obs_floats: int, h: int, w: int) -> int:
+    """N*(41 + 4L) + H*W + 122 bytes per env-step."""
+    return n_agents * (41 + 4 * obs_floats) + h * w + 122

@@ -30,6 +30,8 @@
  *                         <- the private arrays callers and tests read or poke: _positions_arr, _goals_arr, _starts_arr,
  *                            _reached_arr, _completed_once_arr, _blocking_pressure_prev_arr, step_count, _episode_* counters
  *                            (MA-env:83-89, :63-69; read by src/trainers/callbacks.py:111-131,265-307 and main.py:265,314)
+ *   mapf_observe          <- get_obs / get_action_mask / _flatten_observation called on a static state
+ *                                                               MA-env:707-773, :306-328
  *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
  */
 #ifndef MAPF_STEP_H
@@ -171,6 +173,11 @@ int mapf_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *obs /
  * the reset observation. */
 int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
               float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream);
+
+/* observation of every agent from the CURRENT state, nothing is modified: what the reference returns when
+ * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().
+ * obs: device float32 [B][N][L]. */
+int mapf_observe(mapf_handle h, float *obs /* device */, void *stream);
 
 /* read (and clear) the device error record; synchronizes `stream`.  Returns MAPF_OK when no env has
  * failed, else the code of the first failure with its env / agent / offending value. */
