@@ -39,7 +39,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_observe", "mapf_poll_error", "mapf_launch_info",
+    "mapf_step", "mapf_observe", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
 )
 
 
@@ -89,12 +89,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    so_path = os.environ.get("MAPF_LIB", SO_PATH)  # MAPF_LIB: diagnostic builds (e.g. the stamps build)
+    if not os.path.exists(so_path):
         raise MapfLibraryMissing(
-            f"{SO_PATH} is missing: build it with `python -m dl_reference_models_amd.build` "
+            f"{so_path} is missing: build it with `python -m dl_reference_models_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback."
         )
-    L = C.CDLL(SO_PATH)
+    L = C.CDLL(so_path)
     vp, i32 = C.c_void_p, C.c_int32
     L.mapf_version.restype = C.c_uint32
     L.mapf_obs_len.restype = i32
@@ -123,6 +124,8 @@ def load():
     L.mapf_observe.argtypes = [vp, vp, vp]
     L.mapf_poll_error.restype = C.c_int
     L.mapf_poll_error.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.mapf_debug_stamps.restype = C.c_int
+    L.mapf_debug_stamps.argtypes = [vp, vp, i32]
     L.mapf_launch_info.restype = C.c_int
     L.mapf_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L

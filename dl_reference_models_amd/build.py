@@ -17,6 +17,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libmapfstep.so")
 SOURCES = [os.path.join(CSRC, "mapf_step.hip")]
+DEVICE_INCLUDES = [os.path.join(CSRC, "mapf_kernels.inl")]
 HEADERS = [os.path.join(ROOT, "include", "mapf_step.h")]
 
 # NOTE: no -ffast-math -- goal_delta needs the correctly rounded fp32 divide.
@@ -34,7 +35,7 @@ def is_stale() -> bool:
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)
-    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
+    return any(os.path.getmtime(f) > t for f in SOURCES + DEVICE_INCLUDES + HEADERS + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -1,0 +1,1021 @@
+// mapf_kernels.inl -- device code of the MI355X step engine (included by mapf_step.hip).
+//
+// "MA-env:N" = /root/reference/src/environments/reference_model_multi_agent.py line N.
+//
+// Execution shape: one 64-lane wavefront per workgroup.  An env owns a GROUP of LPE consecutive
+// lanes (LPE = power of two >= N); lane a of the group is agent a, so a wave steps 64/LPE envs
+// (N = 64: one wavefront per env; N = 8: eight envs per wave, no idle lanes in the agent phases).
+// A single wave per workgroup means every LDS hand-off below is intra-wave: LDS executes a wave's
+// DS instructions in order, so a compiler-level fence is all the synchronisation that is needed.
+//
+// Cross-lane traffic goes through two 8-byte-per-agent LDS tables per step (written once, then read
+// by every lane of the group in 16-byte chunks), instead of one broadcast per agent pair:
+//   table 1 (move phase)   {old cell, wanted cell}
+//   table 2 (observe phase){old | new<<16, goal | action<<16 | reached<<19 | (dist delta+256)<<20}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device-side data layout
+// ------------------------------------------------------------------------------------------------
+// Agent record, 32 B, array [B][N] (env-major; a wave reads 64 consecutive records = 2 KiB).
+//   w0: pos (row<<8 | col) | goal<<16      w1: start | flags<<16
+//   moved / failed / progress: lock-history shift registers, bit k = flag k steps ago
+struct AgentRec {
+    uint32_t w0, w1;
+    uint64_t moved, failed, progress;
+};
+static_assert(sizeof(AgentRec) == 32, "AgentRec must be 32 bytes");
+
+constexpr int kFlagReached = 1, kFlagCompleted = 2, kFlagPressure = 4;
+constexpr int kScalInts = MAPF_NUM_COUNTERS;  // 16 int32 = 64 B per env
+constexpr uint32_t kNoCell = 0xFFFFu;         // "no target"
+constexpr uint32_t kIdleCell = 0xFFFEu;       // cell of a lane that holds no agent
+
+struct Params {
+    int B, H, W, N, sr, V, L, steps_per_episode;
+    uint32_t flags;
+    int dw, lw, nearby, min_nbrs, eps_floor, hs;
+    float den_r, den_c;
+    int HW;
+    int hash_cap;      // Floyd hash-set size (power of two), numpy: 1 + gen_mask(uint64(1.2 * 2N))
+    int scratch_i16;   // int16 entries of reset scratch per group
+    int ring_stride;   // int16 entries per agent in the distance ring (multiple of 8)
+    int lds_tab_off, lds_stage_off, lds_scratch_off;  // byte offsets into dynamic LDS (rows start at 0)
+    // state
+    AgentRec *agents;
+    int *scal;
+    int16_t *dist_ring;  // [B][N][ring_stride], slot = history row index mod lw
+    uint64_t *rng;
+    const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
+    const uint16_t *free_cells;  // [B][HW], k-th free cell (row-major) as row<<8|col
+    const uint16_t *free_rank;   // [B][HW], row-major rank of a free cell among free cells
+    const int *n_free;           // [B]
+    int *err;                    // [4] code, env, agent, value
+    unsigned long long *dbg;     // diagnostic build only (-DMAPF_STAMPS): [blocks][16] s_memtime stamps
+};
+
+// In-kernel stamps (diagnostic build only; never in the shipped library): lane 0 of each wave records
+// s_memtime at phase boundaries of k_step into Params::dbg, which nothing else reads.
+#ifdef MAPF_STAMPS
+#define MAPF_STAMP(k)                                                                   \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long _t;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16 + (k)] = _t;       \
+    } while (0)
+#else
+#define MAPF_STAMP(k) do { } while (0)
+#endif
+
+// per-launch arguments (passed by value); Params lives in device memory and is read through a
+// __restrict__ pointer so that its fields are scalar-loaded where they are used instead of being
+// held (and spilled) in SGPRs for the whole kernel
+struct Io {
+    const int8_t *actions;
+    float *obs, *rewards;
+    uint8_t *terminated, *truncated;
+    float *info_all;
+    uint8_t *info_agent;
+    float *final_obs;
+    const uint8_t *env_mask;
+    int auto_reset;
+};
+
+// ------------------------------------------------------------------------------------------------
+// group (sub-wave) primitives
+// ------------------------------------------------------------------------------------------------
+template <int LPE>
+__device__ __forceinline__ uint64_t group_mask() {
+    return LPE == 64 ? ~0ull : ((1ull << (LPE & 63)) - 1ull);
+}
+
+template <int LPE>
+__device__ __forceinline__ uint64_t gballot(bool pred, int lane) {
+    uint64_t b = __ballot(pred);
+    if (LPE == 64) return b;
+    return (b >> (lane & ~(LPE - 1))) & group_mask<LPE>();
+}
+
+// OR the per-group bit sets of a wave ballot together (bit i = "some group has agent i set")
+template <int LPE>
+__device__ __forceinline__ uint64_t fold_groups(uint64_t m) {
+    if (LPE <= 32) m |= m >> 32;
+    if (LPE <= 16) m |= m >> 16;
+    if (LPE <= 8) m |= m >> 8;
+    if (LPE <= 4) m |= m >> 4;
+    return m & group_mask<LPE>();
+}
+
+// broadcast lane j of every group (j wave-uniform); only used on rare paths (lifelong respawn)
+template <int LPE>
+__device__ __forceinline__ uint32_t gshfl(uint32_t v, int j) {
+    if (LPE == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, j);
+    return (uint32_t)__shfl((int)v, j, LPE);
+}
+
+// intra-wave LDS hand-off point (one wave per workgroup: DS ops of a wave execute in order)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// V x V window bit masks (bit dr*V+dc); MW = 32 (V <= 5), 64 (V <= 7), 128 (V <= 11)
+// ------------------------------------------------------------------------------------------------
+template <int MW>
+struct WMask;
+template <>
+struct WMask<32> {
+    uint32_t lo;
+    __device__ __forceinline__ void clear() { lo = 0; }
+    __device__ __forceinline__ void set_if(bool c, int b) { lo |= (c ? 1u : 0u) << b; }
+    __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1u; }
+    __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= w << shift; }
+    __device__ __forceinline__ uint32_t nib(int t0) const { return (lo >> t0) & 15u; }
+    __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
+    __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
+};
+template <>
+struct WMask<64> {
+    uint64_t lo;
+    __device__ __forceinline__ void clear() { lo = 0; }
+    __device__ __forceinline__ void set_if(bool c, int b) { lo |= (c ? 1ull : 0ull) << b; }
+    __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1ull; }
+    __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= (uint64_t)w << shift; }
+    __device__ __forceinline__ uint32_t nib(int t0) const { return (uint32_t)(lo >> t0) & 15u; }
+    __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
+    __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
+};
+template <>
+struct WMask<128> {
+    uint64_t lo, hi;
+    __device__ __forceinline__ void clear() { lo = hi = 0; }
+    __device__ __forceinline__ void set_if(bool c, int b) {
+        const uint64_t v = c ? 1ull : 0ull;
+        if (b < 64) lo |= v << b; else hi |= v << (b - 64);
+    }
+    __device__ __forceinline__ bool get(int b) const { return b < 64 ? ((lo >> b) & 1ull) : ((hi >> (b - 64)) & 1ull); }
+    __device__ __forceinline__ void or_row(uint32_t w, int shift) {
+        if (shift < 64) {
+            lo |= (uint64_t)w << shift;
+            if (shift > 0) hi |= (uint64_t)w >> (64 - shift);
+        } else {
+            hi |= (uint64_t)w << (shift - 64);
+        }
+    }
+    // t0 is a multiple of 4, so a nibble never straddles the two words
+    __device__ __forceinline__ uint32_t nib(int t0) const {
+        return (uint32_t)(t0 < 64 ? (lo >> t0) : (hi >> (t0 - 64))) & 15u;
+    }
+    __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo, hi | o.hi}; }
+    __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo, hi & ~o.hi}; }
+};
+
+// V bits of an obstacle row starting at column c0 (may be negative / run past 63); outside = 1
+__device__ __forceinline__ uint32_t row_window(uint64_t ext, int c0, int V) {
+    uint64_t w;
+    if (c0 >= 0) {
+        w = ext >> c0;
+        if (c0 > 0) w |= ~0ull << (64 - c0);
+    } else {
+        w = (ext << (-c0)) | ((1ull << (-c0)) - 1ull);
+    }
+    return (uint32_t)w & ((1u << V) - 1u);
+}
+
+// 4 mask bits -> 4 bytes (bit i -> byte i LSB)
+__device__ __forceinline__ uint32_t spread4(uint32_t n) { return (n * 0x00204081u) & 0x01010101u; }
+
+// ------------------------------------------------------------------------------------------------
+// NumPy Generator(PCG64) on device (numpy 2.2.6: pcg64.h, distributions.c, _generator.pyx)
+// ------------------------------------------------------------------------------------------------
+struct Pcg {
+    uint64_t shi, slo, ihi, ilo;
+    uint32_t has32, uinteger;
+};
+__device__ __forceinline__ void pcg_load(Pcg &g, const uint64_t *w) {
+    g.shi = w[0]; g.slo = w[1]; g.ihi = w[2]; g.ilo = w[3];
+    g.has32 = (uint32_t)w[4]; g.uinteger = (uint32_t)w[5];
+}
+__device__ __forceinline__ void pcg_store(const Pcg &g, uint64_t *w) {
+    w[0] = g.shi; w[1] = g.slo; w[2] = g.ihi; w[3] = g.ilo; w[4] = g.has32; w[5] = g.uinteger;
+}
+__device__ __forceinline__ uint64_t pcg_next64(Pcg &g) {
+    // state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc (mod 2^128); XSL-RR output of the NEW state
+    const uint64_t MH = 0x2360ED051FC65DA4ull, ML = 0x4385DF649FCCF645ull;
+    uint64_t lo = g.slo * ML;
+    uint64_t hi = __umul64hi(g.slo, ML) + g.slo * MH + g.shi * ML;
+    uint64_t nlo = lo + g.ilo;
+    uint64_t nhi = hi + g.ihi + (nlo < lo ? 1ull : 0ull);
+    g.slo = nlo; g.shi = nhi;
+    uint64_t x = nhi ^ nlo;
+    unsigned rot = (unsigned)(nhi >> 58);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+__device__ __forceinline__ uint32_t pcg_next32(Pcg &g) {
+    if (g.has32) { g.has32 = 0; return g.uinteger; }
+    uint64_t n = pcg_next64(g);
+    g.has32 = 1;
+    g.uinteger = (uint32_t)(n >> 32);
+    return (uint32_t)n;
+}
+// random_bounded_uint64(off=0, rng, use_masked=false) for rng < 2^32-1: Lemire with rejection
+__device__ __forceinline__ uint32_t pcg_bounded(Pcg &g, uint32_t rng) {
+    if (rng == 0) return 0;  // no draw
+    const uint32_t excl = rng + 1u;
+    uint64_t m = (uint64_t)pcg_next32(g) * excl;
+    uint32_t left = (uint32_t)m;
+    if (left < excl) {
+        const uint32_t thr = (0xFFFFFFFFu - rng) % excl;
+        // rejection probability per draw is thr / 2^32 < 1e-6 here; the cap only guards against a hang
+        for (int guard = 0; left < thr && guard < 4096; guard++) {
+            m = (uint64_t)pcg_next32(g) * excl;
+            left = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-lane register image of an agent
+// ------------------------------------------------------------------------------------------------
+struct Lane {
+    uint32_t pos, goal, start;  // row<<8|col
+    uint32_t flags;
+    uint64_t moved, failed, progress;
+};
+
+__device__ __forceinline__ void load_lane(const Params &p, int env, int a, bool is_agent, Lane &st) {
+    if (is_agent) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(p.agents + (size_t)env * p.N + a);
+        uint4 q0 = rp[0], q1 = rp[1];
+        st.pos = q0.x & 0xFFFFu;
+        st.goal = q0.x >> 16;
+        st.start = q0.y & 0xFFFFu;
+        st.flags = (q0.y >> 16) & 0xFFu;
+        st.moved = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+        st.failed = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+        st.progress = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+    } else {
+        st.pos = kIdleCell;
+        st.goal = 0xFFFDu;
+        st.start = kIdleCell;
+        st.flags = 0;
+        st.moved = st.failed = st.progress = 0;
+    }
+}
+
+__device__ __forceinline__ void store_lane(const Params &p, int env, int a, const Lane &st) {
+    uint4 *rp = reinterpret_cast<uint4 *>(p.agents + (size_t)env * p.N + a);
+    uint4 q0, q1;
+    q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
+    q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
+    q0.z = (uint32_t)st.moved;
+    q0.w = (uint32_t)(st.moved >> 32);
+    q1.x = (uint32_t)st.failed;
+    q1.y = (uint32_t)(st.failed >> 32);
+    q1.z = (uint32_t)st.progress;
+    q1.w = (uint32_t)(st.progress >> 32);
+    rp[0] = q0;
+    rp[1] = q1;
+}
+
+__device__ __forceinline__ void load_scal(const Params &p, int env, int *sc) {
+    const int4 *sp = reinterpret_cast<const int4 *>(p.scal + (size_t)env * kScalInts);
+    int4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w;
+    sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    sc[8] = s2.x; sc[9] = s2.y; sc[10] = s2.z; sc[11] = s2.w;
+}
+__device__ __forceinline__ void store_scal(const Params &p, int env, const int *sc) {
+    int4 *sp = reinterpret_cast<int4 *>(p.scal + (size_t)env * kScalInts);
+    sp[0] = make_int4(sc[0], sc[1], sc[2], sc[3]);
+    sp[1] = make_int4(sc[4], sc[5], sc[6], sc[7]);
+    sp[2] = make_int4(sc[8], sc[9], sc[10], sc[11]);
+}
+
+template <int LPE>
+__device__ __forceinline__ void load_rows_to_lds(const Params &p, uint64_t *lrows, int lane, int env0, int ngroups) {
+    const int total = ngroups * p.H;
+    const uint64_t *src = p.grid_rows + (size_t)env0 * p.H;
+    for (int k0 = 0; k0 < total; k0 += 256) {
+        uint64_t t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int idx = k0 + u * 64 + lane;
+            t[u] = idx < total ? src[idx] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int idx = k0 + u * 64 + lane;
+            if (idx < total) lrows[idx] = t[u];
+        }
+    }
+}
+
+__device__ __forceinline__ void raise_error(const Params &p, int code, int env, int agent, int value) {
+    if (atomicCAS(&p.err[0], 0, code) == 0) {
+        p.err[1] = env;
+        p.err[2] = agent;
+        p.err[3] = value;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// move phase (MA-env:502-526): agents move in index order against live occupancy.  Restated as a
+// dependency problem: agent i (target T) is blocked iff
+//   - a higher-index agent still stands on T (it has not had its turn yet), or
+//   - a lower-index agent stood on T and did not move away, or
+//   - a lower-index agent with the same target moved into T.
+// Outcomes depend on lower indices only, so they resolve in rounds of two ballots; almost every
+// agent has no dependency at all and the loop ends after one round.
+// ------------------------------------------------------------------------------------------------
+template <int LPE>
+__device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, int lane, int a, uint32_t old,
+                                                  uint32_t tgt) {
+    constexpr int C = LPE < 8 ? LPE : 8;
+    tabg[a] = make_uint2(old, tgt);
+    wave_lds_sync();
+    int occ_by = -1;
+    uint64_t cont = 0;
+    const bool want = tgt != kNoCell;
+    for (int j0 = 0; j0 < p.N; j0 += C) {
+        uint2 e[C];
+#pragma unroll
+        for (int u = 0; u < C; u++) e[u] = tabg[j0 + u];
+#pragma unroll
+        for (int u = 0; u < C; u++) {
+            const int j = j0 + u;
+            const bool vj = j < p.N;
+            if (vj && e[u].x == tgt) occ_by = j;  // positions are unique: at most one occupant
+            if (vj && j < a && want && e[u].y == tgt) cont |= 1ull << j;
+        }
+    }
+    const bool occ_low = occ_by >= 0 && occ_by < a;
+    const uint64_t dep = cont | (occ_low ? (1ull << occ_by) : 0ull);
+    bool resolved = !want, moved = false;
+    uint64_t R = gballot<LPE>(resolved, lane), M = 0;
+    for (int it = 0; it <= p.N; it++) {
+        if (__all(resolved)) break;
+        if (!resolved && (dep & ~R) == 0) {
+            const bool blocked = (occ_by > a) || (occ_low && !((M >> occ_by) & 1ull)) || (cont & M) != 0;
+            moved = !blocked;
+            resolved = true;
+        }
+        R = gballot<LPE>(resolved, lane);
+        M = gballot<LPE>(moved, lane);
+    }
+    wave_lds_sync();  // table may be rewritten after this point
+    return moved ? tgt : old;
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation of every agent lane -> LDS staging row (MA-env:707-747 get_obs, :749-773 mask,
+// :306-335 flatten), fused with the other all-pairs work of a step when FULL: neighbour sets of
+// the lock detector (MA-env:389-398), intent blocking (:608-623), coincidence penalty (:658-666).
+//   table entry of agent j: x = old | new<<16,  y = goal | action<<16 | reached<<19 | (delta+256)<<20
+// final_state: everybody at their new cell (reset, or after a lifelong respawn MA-env:565-575);
+// otherwise agent i sees agents <= i at their new cell and agents > i at their old one (MA-env:528).
+// ------------------------------------------------------------------------------------------------
+struct PairOut {
+    uint64_t nbr;   // agents within lock_nearby_manhattan (final positions), self excluded
+    int sum_delta;  // sum over {self} U nbr of (distance at window start - distance now)
+    bool blocks;    // some not-yet-reached agent intended to enter my cell
+    int coincide;   // agents sharing my cell (0 by invariant)
+};
+
+template <int LPE, int MW, bool FULL>
+__device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, const uint2 *tabg, float *srow,
+                                        bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
+                                        bool pressure, int my_delta, PairOut &po) {
+    constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
+    constexpr int C = LPE < 8 ? LPE : 8;
+    const int V = p.V, sr = p.sr;
+    const int myr = (int)(cur >> 8), myc = (int)(cur & 255u);
+    const int r0 = myr - sr, c0 = myc - sr;
+
+    WMask<MW> obst, agm, own, oth;
+    obst.clear(); agm.clear(); own.clear(); oth.clear();
+
+    uint64_t rows[MAXV];
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {
+        const int r = r0 + d;
+        const bool in = (d < V) && r >= 0 && r < p.H && is_agent;
+        const uint64_t v = lrows[in ? r : 0];
+        rows[d] = in ? v : ~0ull;
+    }
+
+    po.nbr = 0;
+    po.sum_delta = my_delta;
+    po.blocks = false;
+    po.coincide = 0;
+    for (int j0 = 0; j0 < p.N; j0 += C) {
+        uint2 e[C];
+#pragma unroll
+        for (int u = 0; u < C; u++) e[u] = tabg[j0 + u];
+#pragma unroll
+        for (int u = 0; u < C; u++) {
+            const int j = j0 + u;
+            const bool vj = j < p.N;
+            const uint32_t Aj = e[u].x, Bj = e[u].y;
+            const uint32_t oldj = Aj & 0xFFFFu, newj = Aj >> 16;
+            const uint32_t pj = (final_state || j <= a) ? newj : oldj;
+            const int pr = (int)(pj >> 8) - r0, pc = (int)(pj & 255u) - c0;
+            agm.set_if(vj && j != a && (unsigned)pr < (unsigned)V && (unsigned)pc < (unsigned)V, pr * V + pc);
+            const int gr = (int)((Bj >> 8) & 255u) - r0, gc = (int)(Bj & 255u) - c0;
+            const bool gin = vj && (unsigned)gr < (unsigned)V && (unsigned)gc < (unsigned)V;
+            own.set_if(gin && j == a, gr * V + gc);
+            oth.set_if(gin && j != a, gr * V + gc);
+            if (FULL) {
+                const int d = abs((int)(newj >> 8) - myr) + abs((int)(newj & 255u) - myc);
+                if (vj && d > 0 && d <= p.nearby) {
+                    po.nbr |= 1ull << j;
+                    po.sum_delta += (int)((Bj >> 20) & 1023u) - 256;
+                }
+                const int actj = (int)((Bj >> 16) & 7u);
+                const int ir = (int)(oldj >> 8) + ((actj == 1) ? -1 : ((actj == 3) ? 1 : 0));
+                const int ic = (int)(oldj & 255u) + ((actj == 2) ? 1 : ((actj == 4) ? -1 : 0));
+                if (vj && j != a && !((Bj >> 19) & 1u) && ir == myr && ic == myc) po.blocks = true;
+                if (vj && j != a && newj == cur) po.coincide += 1;
+            }
+        }
+    }
+    if (!is_agent) return;
+
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {
+        if (d < V) obst.or_row(row_window(rows[d], c0, V), d * V);
+    }
+
+    // cell code priority: obstacle / out-of-bounds 1 > other agent 2 > own goal 3 > other goal 4 > empty 0,
+    // as three bit planes; four cells are converted per round (bit spread + byte->float converts)
+    const WMask<MW> oa = obst | agm;
+    const WMask<MW> g3 = own.andnot(oa);
+    const WMask<MW> g4 = oth.andnot(oa | own);
+    const WMask<MW> bit0 = obst | g3;
+    const WMask<MW> bit1 = agm.andnot(obst) | g3;
+    const int VV = V * V;
+    for (int t0 = 0; t0 < VV; t0 += 4) {
+        const uint32_t by = spread4(bit0.nib(t0)) | (spread4(bit1.nib(t0)) << 1) | (spread4(g4.nib(t0)) << 2);
+        srow[t0] = (float)(by & 0xFFu);
+        if (t0 + 1 < VV) srow[t0 + 1] = (float)((by >> 8) & 0xFFu);
+        if (t0 + 2 < VV) srow[t0 + 2] = (float)((by >> 16) & 0xFFu);
+        if (t0 + 3 < VV) srow[t0 + 3] = (float)(by >> 24);
+    }
+    float *q = srow + VV;
+    float gd_r = (float)((int)((goal >> 8) & 255u) - myr);
+    float gd_c = (float)((int)(goal & 255u) - myc);
+    if (p.flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) {
+        gd_r = gd_r / p.den_r;
+        gd_c = gd_c / p.den_c;
+    }
+    *q++ = gd_r;
+    *q++ = gd_c;
+    if (p.flags & MAPF_FLAG_GOAL_DISTANCE) *q++ = fabsf(gd_r) + fabsf(gd_c);
+    if (p.flags & MAPF_FLAG_BLOCKING_PRESSURE) *q++ = pressure ? 1.0f : 0.0f;
+    if (p.flags & MAPF_FLAG_ACTION_MASK) {
+        const int ctr = sr * V + sr;
+        bool up = false, rt = false, dn = false, lf = false;
+        if (sr > 0) {
+            up = !oa.get(ctr - V);
+            rt = !oa.get(ctr + 1);
+            dn = !oa.get(ctr + V);
+            lf = !oa.get(ctr - 1);
+        }
+        q[0] = 1.0f;
+        q[1] = up ? 1.0f : 0.0f;
+        q[2] = rt ? 1.0f : 0.0f;
+        q[3] = dn ? 1.0f : 0.0f;
+        q[4] = lf ? 1.0f : 0.0f;
+    }
+}
+
+// copy the wave's staged observations to global memory.  sel (per lane, uniform inside a group):
+// 0 -> io.obs, 1 -> io.final_obs, 2 -> skip.  Flat 16-byte stores when every valid group goes to
+// the same tensor, otherwise one contiguous run per group.
+template <int LPE>
+__device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const float *stage, int lane, int env0, int ngroups, int sel) {
+    constexpr int G = 64 / LPE;
+    const int NL = p.N * p.L;
+    const uint64_t valid = __ballot((lane / LPE) < ngroups);
+    const uint64_t m0 = __ballot((lane / LPE) < ngroups && sel == 0);
+    const uint64_t m1 = __ballot((lane / LPE) < ngroups && sel == 1);
+    if ((m0 | m1) == 0) return;
+    if (m0 == valid || m1 == valid) {
+        float *flat = m0 == valid ? io.obs : io.final_obs;
+        if (!flat) return;
+        const int n = ngroups * NL;
+        float *dst = flat + (size_t)env0 * NL;
+        if (((G * NL) & 3) == 0) {
+            const int n4 = n >> 2;
+            const float4 *s4 = reinterpret_cast<const float4 *>(stage);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            for (int k = lane; k < n4; k += 64) d4[k] = s4[k];
+            for (int k = (n4 << 2) + lane; k < n; k += 64) dst[k] = stage[k];
+        } else {
+            for (int k = lane; k < n; k += 64) dst[k] = stage[k];
+        }
+        return;
+    }
+    for (int g = 0; g < ngroups; g++) {
+        const int sg = __shfl(sel, g * LPE, 64);
+        float *base = sg == 0 ? io.obs : (sg == 1 ? io.final_obs : nullptr);
+        if (!base) continue;
+        float *dst = base + (size_t)(env0 + g) * NL;
+        const float *src = stage + g * NL;
+        for (int k = lane; k < NL; k += 64) dst[k] = src[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset() of the groups with do_reset set (MA-env:440-472).  Group-uniform inputs; called under a
+// wave-uniform branch.  Updates lane state + scalars; stages the reset observation when want_obs.
+// ------------------------------------------------------------------------------------------------
+template <int LPE, int MW>
+__device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lrows, uint2 *tab, float *stage,
+                                             int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
+                                             bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs) {
+    if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) {
+        // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False)
+        int16_t *hs = scratch + grp * p.scratch_i16;
+        int16_t *out = hs + p.hash_cap;
+        if (do_reset && a == 0) {
+            Pcg g;
+            pcg_load(g, p.rng + (size_t)env * 6);
+            const int mask = p.hash_cap - 1, size = 2 * p.N, pop = p.n_free[env];
+            for (int k = 0; k < p.hash_cap; k++) hs[k] = -1;
+            for (int j = pop - size; j < pop; j++) {  // Floyd
+                int val = (int)pcg_bounded(g, (uint32_t)j);
+                int loc = val & mask;
+                // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
+                // probe counters only make termination structural
+                for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < p.hash_cap; pr++) loc = (loc + 1) & mask;
+                if (hs[loc] == -1) {
+                    hs[loc] = (int16_t)val;
+                    out[j - pop + size] = (int16_t)val;
+                } else {
+                    loc = j & mask;
+                    for (int pr = 0; hs[loc] != -1 && pr < p.hash_cap; pr++) loc = (loc + 1) & mask;
+                    hs[loc] = (int16_t)j;
+                    out[j - pop + size] = (int16_t)j;
+                }
+            }
+            for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
+                int j = (int)pcg_bounded(g, (uint32_t)i);
+                int16_t t = out[j];
+                out[j] = out[i];
+                out[i] = t;
+            }
+            if (env_ok) pcg_store(g, p.rng + (size_t)env * 6);
+        }
+        wave_lds_sync();
+        if (do_reset && is_agent) {
+            const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+            st.start = fc[out[a]];
+            st.goal = fc[out[p.N + a]];
+        }
+        wave_lds_sync();
+    }
+    if (do_reset) {
+        st.pos = st.start;  // MA-env:279 / :453
+        st.flags = 0;       // _reached_arr, _completed_once_arr, _blocking_pressure_prev_arr MA-env:447-449
+        st.moved = st.failed = st.progress = 0;  // _reset_lock_tracking MA-env:360-372
+        sc[MAPF_CTR_STEP_COUNT] = 0;
+        sc[MAPF_CTR_HIST_ROWS] = 0;
+        sc[MAPF_CTR_BLOCKING_COUNT] = 0;
+        sc[MAPF_CTR_GOALS_REACHED_TOTAL] = 0;
+        sc[MAPF_CTR_DEADLOCK_EVENTS] = 0;
+        sc[MAPF_CTR_LIVELOCK_EVENTS] = 0;
+        sc[MAPF_CTR_DEADLOCK_STEPS] = 0;
+        sc[MAPF_CTR_LIVELOCK_STEPS] = 0;
+        sc[MAPF_CTR_LOCK_STATE_PREV] = 0;
+    }
+    if (want_obs) {
+        uint2 *tabg = tab + grp * LPE;
+        tabg[a] = make_uint2(st.pos | (st.pos << 16), st.goal);
+        wave_lds_sync();
+        PairOut po;
+        observe<LPE, MW, false>(p, lrows + grp * p.H, tabg, stage + (size_t)(grp * p.N + a) * p.L, is_agent && do_reset,
+                                a, st.pos, st.goal, true, false, 0, po);
+        wave_lds_sync();
+    }
+}
+
+// LDS carve-up shared by the three kernels
+struct Lds {
+    uint64_t *rows;
+    uint2 *tab;
+    float *stage;
+    int16_t *scratch;
+};
+__device__ __forceinline__ Lds carve_lds(const Params &p, unsigned char *raw) {
+    Lds l;
+    l.rows = reinterpret_cast<uint64_t *>(raw);
+    l.tab = reinterpret_cast<uint2 *>(raw + p.lds_tab_off);
+    l.stage = reinterpret_cast<float *>(raw + p.lds_stage_off);
+    l.scratch = reinterpret_cast<int16_t *>(raw + p.lds_scratch_off);
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset kernel
+// ------------------------------------------------------------------------------------------------
+template <int LPE, int MW>
+__global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, const Io io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Lds l = carve_lds(p, lds_raw);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, p.B - env0);
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : p.B - 1;
+    const bool is_agent = env_ok && a < p.N;
+
+    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    Lane st;
+    load_lane(p, env, a, is_agent, st);
+    int sc[12];
+    load_scal(p, env, sc);
+    const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
+    wave_lds_sync();
+
+    reset_groups<LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
+                          io.obs != nullptr);
+    if (io.obs) flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
+    if (do_reset) {
+        if (is_agent) store_lane(p, env, a, st);
+        if (a == 0) store_scal(p, env, sc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// observe kernel: observation of every agent from the current (static) state, nothing is modified.
+// What the reference computes when get_obs / _flatten_observation are called outside step()
+// (its tests do: tests/test_reference_model_multi_agent_invariants.py:76-95).
+// ------------------------------------------------------------------------------------------------
+template <int LPE, int MW>
+__global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, const Io io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Lds l = carve_lds(p, lds_raw);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, p.B - env0);
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : p.B - 1;
+    const bool is_agent = env_ok && a < p.N;
+    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    Lane st;
+    load_lane(p, env, a, is_agent, st);
+    uint2 *tabg = l.tab + grp * LPE;
+    tabg[a] = make_uint2(st.pos | (st.pos << 16), st.goal);
+    wave_lds_sync();
+    PairOut po;
+    observe<LPE, MW, false>(p, l.rows + grp * p.H, tabg, l.stage + (size_t)(grp * p.N + a) * p.L, is_agent, a, st.pos,
+                            st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
+    wave_lds_sync();
+    flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// step kernel (MA-env:474-695)
+// ------------------------------------------------------------------------------------------------
+template <int LPE, int MW>
+__global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Lds l = carve_lds(p, lds_raw);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, p.B - env0);
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : p.B - 1;
+    const bool is_agent = env_ok && a < p.N;
+    const int N = p.N;
+    const bool lifelong = (p.flags & MAPF_FLAG_LIFELONG) != 0;
+    const bool lock_on = (p.flags & MAPF_FLAG_LOCK_METRICS) != 0;
+    uint2 *tabg = l.tab + grp * LPE;
+    const uint64_t *myrows = l.rows + grp * p.H;
+
+    MAPF_STAMP(0);
+    // ---- loads: obstacle rows -> LDS, agent record, env scalars, action, distance ring; all in flight together
+    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    Lane st;
+    load_lane(p, env, a, is_agent, st);
+    int sc[12];
+    load_scal(p, env, sc);
+    int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
+    const bool ring_pre = lock_on && p.ring_stride <= 16;  // whole per-agent ring fits two 16-byte loads
+    int16_t *ring = p.dist_ring + ((size_t)env * N + a) * p.ring_stride;
+    uint4 rq0 = make_uint4(0, 0, 0, 0), rq1 = make_uint4(0, 0, 0, 0);
+    if (ring_pre && is_agent) {
+        rq0 = reinterpret_cast<const uint4 *>(ring)[0];
+        if (p.ring_stride > 8) rq1 = reinterpret_cast<const uint4 *>(ring)[1];
+    }
+    wave_lds_sync();
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
+#endif
+    MAPF_STAMP(1);
+
+    // ---- invalid action: the reference raises mid-loop, after the agents before the bad one were
+    //      processed (MA-env:502-506); reproduce the partial mutation and latch the error ---------
+    const bool bad = is_agent && (act < 0 || act > 4);
+    const uint64_t badm = gballot<LPE>(bad, lane);
+    const bool errored = badm != 0;
+    const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+    const bool live = is_agent && a < n_live;
+    if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
+    if (!live) act = 0;
+
+    sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
+
+    // ---- move phase (MA-env:502-526) -----------------------------------------------------------
+    const uint32_t old = st.pos;
+    const int r_old = (int)(old >> 8), c_old = (int)(old & 255u);
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const int tr = r_old + dr, tc = c_old + dc;
+    const bool inb = tr >= 0 && tr < p.H && tc >= 0 && tc < p.W;
+    const uint64_t trow = (live && inb) ? myrows[tr] : ~0ull;
+    const bool want = live && act != 0 && inb && !((trow >> tc) & 1ull);
+    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    uint32_t cur = old;
+    if (__any(want)) cur = resolve_moves<LPE>(p, tabg, lane, a, old, tgt);
+    const bool moved = cur != old;
+    MAPF_STAMP(2);
+
+    // ---- goal / reward logic (MA-env:538-563) --------------------------------------------------
+    bool reached = (st.flags & kFlagReached) != 0;
+    bool completed = (st.flags & kFlagCompleted) != 0;
+    const bool pressure_prev = (st.flags & kFlagPressure) != 0;
+    float reward = 0.0f;
+    bool grs = false;                      // goal_reached_step flag
+    bool on_goal = live && cur == st.goal;  // reached_goal[i], evaluated at agent i's own turn
+    bool reassigned = false;                // group-uniform: any lifelong respawn this step
+    if (!lifelong) {
+        if (on_goal && !reached) {
+            reached = true;
+            completed = true;
+            reward += 0.5f;
+            grs = true;
+        }
+        sc[MAPF_CTR_GOALS_REACHED_TOTAL] += __popcll(gballot<LPE>(grs, lane));
+    } else {
+        const uint64_t arr_wave = __ballot(on_goal);
+        if (arr_wave) {  // wave-uniform, rare
+            const uint64_t garr = gballot<LPE>(on_goal, lane);
+            reassigned = garr != 0;
+            Pcg g;
+            pcg_load(g, p.rng + (size_t)env * 6);
+            const int F = p.n_free[env];
+            const uint16_t *frank = p.free_rank + (size_t)env * p.HW;
+            uint64_t u = fold_groups<LPE>(arr_wave);
+            while (u) {  // respawns happen in agent order, each sees the state "at time i" (MA-env:554)
+                const int i = (int)__builtin_ctzll(u);
+                u &= u - 1;
+                const bool gact = (garr >> i) & 1ull;
+                // occupied cells at time i; goals of everybody else (own old goal is released first, MA-env:286-288)
+                const uint32_t P = is_agent ? ((a <= i) ? cur : old) : kIdleCell;
+                const bool Gact = is_agent && a != i;
+                const int rankP = is_agent ? (int)frank[(P >> 8) * p.W + (P & 255u)] : 0x7FFFFFFF;
+                const int rankG = Gact ? (int)frank[(st.goal >> 8) * p.W + (st.goal & 255u)] : 0x7FFFFFFF;
+                bool dup = false;  // my goal cell is also occupied -> count it once
+                for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(P, q) == st.goal);
+                dup = dup && Gact;
+                const int overlap = __popcll(gballot<LPE>(dup, lane));
+                const int k = F - N - (N - 1) + overlap;  // candidate_indices.size MA-env:295
+                uint32_t r = 0;
+                if (gact) {
+                    if (k <= 0) {
+                        if (a == i) raise_error(p, MAPF_ERR_NO_RESPAWN, env, i, k);
+                    } else {
+                        r = pcg_bounded(g, (uint32_t)(k - 1));  // rng.integers(k) MA-env:300
+                    }
+                }
+                // r-th candidate in row-major order = free-rank y with y = r + #{excluded ranks <= y}
+                int y = (int)r;
+                for (int it = 0; it <= 2 * N; it++) {  // converges in <= #excluded + 1 rounds
+                    int cnt = __popcll(gballot<LPE>(is_agent && rankP <= y, lane)) +
+                              __popcll(gballot<LPE>(Gact && !dup && rankG <= y, lane));
+                    int y2 = (int)r + cnt;
+                    bool changed = gact && k > 0 && y2 != y;
+                    y = y2;
+                    if (!__any(changed)) break;
+                }
+                if (gact && k > 0 && a == i) st.goal = p.free_cells[(size_t)env * p.HW + y];  // MA-env:301-303
+            }
+            if (reassigned && a == 0 && env_ok) pcg_store(g, p.rng + (size_t)env * 6);
+            if (on_goal) {  // MA-env:547-556
+                reward += 0.5f;
+                grs = true;
+                completed = true;
+                reached = false;
+                on_goal = false;  // reached_goal[i] = False after the respawn
+            }
+            sc[MAPF_CTR_GOALS_REACHED_TOTAL] += __popcll(garr);
+        }
+    }
+
+    // ---- everything below is skipped by the reference when the ValueError fired; such groups keep
+    //      only the mutations made before the exception ----------------------------------------------
+    int sc_keep[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) sc_keep[k] = sc[k];
+    const uint64_t h_moved = st.moved, h_failed = st.failed, h_progress = st.progress;
+
+    // lock flags (MA-env:581-594) and distance ring
+    const int gr_ = (int)((st.goal >> 8) & 255u), gc_ = (int)(st.goal & 255u);
+    const int r_new = (int)(cur >> 8), c_new = (int)(cur & 255u);
+    const bool cur_on_goal = is_agent && cur == st.goal;
+    const bool prev_on_goal = !lifelong && old == st.goal;
+    const bool progress = lifelong ? grs : (!prev_on_goal && cur_on_goal);
+    const bool failed = act != 0 && !moved;
+    const int dist = abs(gr_ - r_new) + abs(gc_ - c_new);
+    int delta = 0;
+    bool dl_ok = false, ll_ok = false;
+    if (lock_on) {
+        const int t = sc[MAPF_CTR_HIST_ROWS];
+        const int count = min(t + 1, p.hs);
+        dl_ok = count >= p.dw;
+        ll_ok = count >= p.lw;
+        st.moved = (st.moved << 1) | (moved ? 1ull : 0ull);  // _append_lock_history_step MA-env:374-387
+        st.failed = (st.failed << 1) | (failed ? 1ull : 0ull);
+        st.progress = (st.progress << 1) | (progress ? 1ull : 0ull);
+        const int slot_new = t % p.lw, slot_old = (t + 1) % p.lw;  // oldest row of the livelock window
+        int d_old = dist;
+        if (p.lw > 1 && ll_ok) {
+            if (ring_pre) {
+                const int dwi = slot_old >> 1;
+                uint32_t w = rq0.x;
+                w = dwi == 1 ? rq0.y : w;
+                w = dwi == 2 ? rq0.z : w;
+                w = dwi == 3 ? rq0.w : w;
+                w = dwi == 4 ? rq1.x : w;
+                w = dwi == 5 ? rq1.y : w;
+                w = dwi == 6 ? rq1.z : w;
+                w = dwi == 7 ? rq1.w : w;
+                d_old = (int)((slot_old & 1) ? (w >> 16) : (w & 0xFFFFu));
+            } else if (is_agent) {
+                d_old = ring[slot_old];
+            }
+        }
+        if (is_agent && !errored) ring[slot_new] = (int16_t)dist;
+        delta = d_old - dist;
+        sc[MAPF_CTR_HIST_ROWS] = t + 1;
+    }
+
+    // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
+    // neighbour / blocking / coincidence pass
+    tabg[a] = make_uint2(old | (cur << 16), (st.goal & 0xFFFFu) | ((uint32_t)act << 16) | ((reached ? 1u : 0u) << 19) |
+                                                ((uint32_t)(delta + 256) << 20));
+    wave_lds_sync();
+    MAPF_STAMP(3);
+    PairOut po;
+    observe<LPE, MW, true>(p, myrows, tabg, l.stage + (size_t)(grp * N + a) * p.L, is_agent, a, cur, st.goal, reassigned,
+                           pressure_prev, delta, po);
+    MAPF_STAMP(4);
+    reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
+
+    // lock detector (MA-env:400-438): deadlock has priority over livelock
+    int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
+    if (lock_on) {
+        const uint64_t mdw = p.dw >= 64 ? ~0ull : ((1ull << p.dw) - 1ull);
+        const uint64_t mlw = p.lw >= 64 ? ~0ull : ((1ull << p.lw) - 1ull);
+        const uint64_t members = po.nbr | (1ull << a);
+        const bool focal = is_agent && !cur_on_goal && __popcll(po.nbr) >= p.min_nbrs;
+        const uint64_t prog_dw_nz = gballot<LPE>(is_agent && (st.progress & mdw) != 0, lane);
+        const uint64_t moved_dw_nz = gballot<LPE>(is_agent && (st.moved & mdw) != 0, lane);
+        const uint64_t fail_dw_nz = gballot<LPE>(is_agent && (st.failed & mdw) != 0, lane);
+        const uint64_t prog_lw_nz = gballot<LPE>(is_agent && (st.progress & mlw) != 0, lane);
+        const uint64_t moved_lw_nz = gballot<LPE>(is_agent && (st.moved & mlw) != 0, lane);
+        const bool dead_me = focal && dl_ok && (members & prog_dw_nz) == 0 && (members & moved_dw_nz) == 0 &&
+                             (members & fail_dw_nz) != 0;
+        const bool live_me = focal && ll_ok && (members & prog_lw_nz) == 0 && (members & moved_lw_nz) != 0 &&
+                             po.sum_delta <= p.eps_floor;
+        deadlock = gballot<LPE>(dead_me, lane) != 0;
+        livelock = !deadlock && gballot<LPE>(live_me, lane) != 0;
+        const int prev = sc[MAPF_CTR_LOCK_STATE_PREV];
+        dl_event = deadlock && !(prev & 1);  // rising edges MA-env:599-600
+        ll_event = livelock && !(prev & 2);
+        sc[MAPF_CTR_LOCK_STATE_PREV] = deadlock | (livelock << 1);
+        sc[MAPF_CTR_DEADLOCK_STEPS] += deadlock;
+        sc[MAPF_CTR_LIVELOCK_STEPS] += livelock;
+        sc[MAPF_CTR_DEADLOCK_EVENTS] += dl_event;
+        sc[MAPF_CTR_LIVELOCK_EVENTS] += ll_event;
+    }
+
+    // blocking flags feed NEXT step's observation (MA-env:608-625)
+    const bool blocking = is_agent && reached && !moved && po.blocks;
+    const int blocking_step = __popcll(gballot<LPE>(blocking, lane));
+    sc[MAPF_CTR_BLOCKING_COUNT] += blocking_step;
+
+    // termination (MA-env:668-690): success check precedes the step-limit check
+    int term = 0, trunc = 0;
+    const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+    if (!lifelong && n_on_goal == N) {
+        reward += 1.0f;
+        term = 1;
+    } else if (sc[MAPF_CTR_STEP_COUNT] >= p.steps_per_episode) {
+        if (!lifelong && !on_goal) reward -= 1.0f;
+        term = 1;
+        trunc = 1;
+    }
+    const bool done = env_ok && !errored && (term | trunc);
+    const bool do_reset = done && io.auto_reset;
+
+    // ---- observations leave the wave as one contiguous stream ------------------------------------
+    wave_lds_sync();
+    MAPF_STAMP(5);
+    if (io.obs || io.final_obs) {
+        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
+        flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, sel);
+    }
+
+    MAPF_STAMP(6);
+    // ---- per-step outputs: info (MA-env:627-656), rewards, done flags --------------------------------
+    {
+        const int goals_step = __popcll(gballot<LPE>(grs, lane));
+        const int reached_cnt = __popcll(gballot<LPE>(is_agent && reached, lane));
+        const int completed_cnt = __popcll(gballot<LPE>(is_agent && completed, lane));
+        const int goals_total = lifelong ? sc[MAPF_CTR_GOALS_REACHED_TOTAL] : reached_cnt;
+        if (io.info_all && env_ok && !errored) {
+            const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
+            for (int k = a; k < MAPF_INFO_ALL; k += LPE) {
+                float v;
+                switch (k) {
+                    case 0: v = (float)goals_step; break;
+                    case 1: v = (float)goals_total; break;
+                    case 2: v = (float)blocking_step; break;
+                    case 3: v = (float)sc[MAPF_CTR_BLOCKING_COUNT]; break;
+                    case 4: v = (float)deadlock; break;
+                    case 5: v = (float)livelock; break;
+                    case 6: v = (float)dl_event; break;
+                    case 7: v = (float)ll_event; break;
+                    case 8: v = (float)sc[MAPF_CTR_DEADLOCK_EVENTS]; break;
+                    case 9: v = (float)sc[MAPF_CTR_LIVELOCK_EVENTS]; break;
+                    case 10: v = (float)sc[MAPF_CTR_DEADLOCK_STEPS]; break;
+                    case 11: v = (float)sc[MAPF_CTR_LIVELOCK_STEPS]; break;
+                    case 12: v = (float)completed_cnt / (float)N; break;  // completion_ratio MA-env:638
+                    default: v = (float)goals_total / (float)steps; break;  // throughput MA-env:655
+                }
+                io.info_all[(size_t)env * MAPF_INFO_ALL + k] = v;
+            }
+        }
+        if (is_agent && !errored) {
+            if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
+            if (io.info_agent) {
+                uchar2 ia;
+                ia.x = blocking ? 1 : 0;
+                ia.y = grs ? 1 : 0;
+                reinterpret_cast<uchar2 *>(io.info_agent)[(size_t)env * N + a] = ia;
+            }
+        }
+        if (env_ok && !errored && a == 0) {
+            if (io.terminated) io.terminated[env] = (uint8_t)term;
+            if (io.truncated) io.truncated[env] = (uint8_t)trunc;
+        }
+    }
+
+    MAPF_STAMP(7);
+    // ---- state image after the step -----------------------------------------------------------
+    st.pos = cur;
+    if (errored) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) sc[k] = sc_keep[k];
+        st.moved = h_moved;
+        st.failed = h_failed;
+        st.progress = h_progress;
+        st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (pressure_prev ? kFlagPressure : 0);
+    } else {
+        st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+    }
+
+    // ---- auto-reset of finished envs (reference harness loop scripts/benchmark_multi_agent_env.py:89-95:
+    //      reset() right after a done step) ------------------------------------------------------------
+    if (__any(do_reset)) {
+        if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
+        wave_lds_sync();
+        reset_groups<LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
+                              io.obs != nullptr);
+        if (io.obs) flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
+    }
+    if (is_agent) store_lane(p, env, a, st);
+    if (env_ok && a == 0) store_scal(p, env, sc);
+    MAPF_STAMP(8);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
+#endif
+    MAPF_STAMP(9);
+}
+
+}  // namespace

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase wave time of k_step from in-kernel s_memtime stamps.
+
+Builds a SEPARATE library with -DMAPF_STAMPS (never the shipped one), runs the c3 workload and prints
+the median cycles each phase takes.  Shares only; the stamped build's run time is not representative.
+"""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "gpurun_out", "libmapfstep_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+                "-DMAPF_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so,
+                os.path.join(ROOT, "dl_reference_models_amd", "csrc", "mapf_step.hip")], check=True)
+os.environ["MAPF_LIB"] = so
+import torch
+from dl_reference_models_amd import workloads as wl
+from dl_reference_models_amd.vec_env import VecReferenceModel
+name = sys.argv[1] if len(sys.argv) > 1 else wl.HEADLINE
+b = wl.WORKLOADS[name][0]
+cfg = wl.workload_config(name, list(range(b)))
+env = VecReferenceModel(cfg)
+env.reset()
+acts = torch.randint(0, 5, (64, b, cfg["num_agents"]), dtype=torch.int8, device=env.device)
+for t in range(130):
+    env.step(acts[t % 64])
+torch.cuda.synchronize()
+blocks = env.launch_info()["blocks"]
+rows = []
+for t in range(20):
+    env.step(acts[t % 64])
+    buf = np.zeros(blocks * 16, dtype=np.uint64)
+    n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert n == buf.size, n
+    rows.append(buf.reshape(blocks, 16)[:, :10].astype(np.int64))
+st = np.stack(rows)  # [T, blocks, 10]
+d = np.diff(st, axis=2)
+names = ["loads+sync", "move", "goal/lock/table", "pair loop+emit", "lock/term ballots", "flush obs", "outputs",
+         "state stores", "drain stores"]
+tot = st[:, :, 9] - st[:, :, 0]
+print(f"workload {name}: {blocks} waves; s_memtime ticks are shader cycles (100 MHz-based clock on gfx950: see guide)")
+for k, nme in enumerate(names):
+    print(f"  {nme:22s} median {np.median(d[:, :, k]):9.0f}  mean {d[:, :, k].mean():9.0f}  p95 {np.percentile(d[:, :, k], 95):9.0f}")
+print(f"  {'wave total':22s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f}")
+start = st[:, :, 0] - st[:, :, 0].min(axis=1, keepdims=True)
+end = st[:, :, 9] - st[:, :, 0].min(axis=1, keepdims=True)
+print(f"  first->last wave start spread: median {np.median(start.max(axis=1)):.0f}; kernel span (first start -> last end) median {np.median(end.max(axis=1)):.0f}")
