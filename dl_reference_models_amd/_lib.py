@@ -26,6 +26,7 @@ FLAG_BLOCKING_PRESSURE = 8
 FLAG_LIFELONG = 16
 FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
+FLAG_GENERIC_KERNEL = 0x80000000
 
 INFO_ALL = 14
 NUM_COUNTERS = 16

@@ -8,10 +8,18 @@
 // A single wave per workgroup means every LDS hand-off below is intra-wave: LDS executes a wave's
 // DS instructions in order, so a compiler-level fence is all the synchronisation that is needed.
 //
-// Cross-lane traffic goes through two 8-byte-per-agent LDS tables per step (written once, then read
-// by every lane of the group in 16-byte chunks), instead of one broadcast per agent pair:
-//   table 1 (move phase)   {old cell, wanted cell}
-//   table 2 (observe phase){old | new<<16, goal | action<<16 | reached<<19 | (dist delta+256)<<20}
+// Cross-lane traffic goes through two LDS tables per step (one entry per lane, written once, then
+// read by every lane of the group with 16-byte reads), instead of one broadcast per agent pair:
+//   move table     {old cell, wanted cell}                                         (8 B / agent)
+//   pair table     {old | new<<16, goal | reached<<16 | (dist delta+256)<<17,
+//                   intended cell (+1,+1) or ~0 when the agent has reached its goal}   (16 B / agent)
+// Lanes that hold no agent publish sentinel entries that fail every test, so the pair loops carry no
+// "is this a real agent" predicate.
+//
+// With one wave per SIMD the kernel is instruction-issue bound (measured: profiles/r01), so the env
+// configuration is a template policy: KFixed<...> turns agent count, sensor range, observation layout,
+// flags and lock windows into compile-time constants for the BASELINE.json shapes, KRuntime keeps
+// every other configuration working from the same source.
 
 namespace {
 
@@ -30,29 +38,46 @@ static_assert(sizeof(AgentRec) == 32, "AgentRec must be 32 bytes");
 constexpr int kFlagReached = 1, kFlagCompleted = 2, kFlagPressure = 4;
 constexpr int kScalInts = MAPF_NUM_COUNTERS;  // 16 int32 = 64 B per env
 constexpr uint32_t kNoCell = 0xFFFFu;         // "no target"
-constexpr uint32_t kIdleCell = 0xFFFEu;       // cell of a lane that holds no agent
+constexpr uint32_t kIdleCell = 0xFFFEu;       // cell of a lane that holds no agent (row 255: far from any grid)
+constexpr uint32_t kIdleGoal = 0xFFFDu;
 
+// Engine constants, resident in device memory and read through a __restrict__ pointer (scalar loads
+// at the point of use; a by-value struct this size is held in SGPRs for the whole kernel and spills).
 struct Params {
-    int B, H, W, N, sr, V, L, steps_per_episode;
+    int B, H, W, N;
+    int sr, V, L, steps_per_episode;
     uint32_t flags;
-    int dw, lw, nearby, min_nbrs, eps_floor, hs;
+    int dw, lw, nearby, min_nbrs, eps_floor, hs, ring_stride;
     float den_r, den_c;
     int HW;
     int hash_cap;      // Floyd hash-set size (power of two), numpy: 1 + gen_mask(uint64(1.2 * 2N))
     int scratch_i16;   // int16 entries of reset scratch per group
-    int ring_stride;   // int16 entries per agent in the distance ring (multiple of 8)
     int lds_tab_off, lds_stage_off, lds_scratch_off;  // byte offsets into dynamic LDS (rows start at 0)
-    // state
-    AgentRec *agents;
-    int *scal;
-    int16_t *dist_ring;  // [B][N][ring_stride], slot = history row index mod lw
+    // cold state (reset / respawn / error paths)
     uint64_t *rng;
-    const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
     const uint16_t *free_cells;  // [B][HW], k-th free cell (row-major) as row<<8|col
     const uint16_t *free_rank;   // [B][HW], row-major rank of a free cell among free cells
     const int *n_free;           // [B]
     int *err;                    // [4] code, env, agent, value
     unsigned long long *dbg;     // diagnostic build only (-DMAPF_STAMPS): [blocks][16] s_memtime stamps
+};
+
+// kernel arguments passed by value: the hot state arrays (as kernel arguments they are known to be
+// global-address-space pointers; pointers read out of Params are generic and compile to flat_* ops)
+// and the per-launch io tensors
+struct Io {
+    AgentRec *agents;
+    int *scal;
+    int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw
+    const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
+    const int8_t *actions;
+    float *obs, *rewards;
+    uint8_t *terminated, *truncated;
+    float *info_all;
+    uint8_t *info_agent;
+    float *final_obs;
+    const uint8_t *env_mask;
+    int auto_reset;
 };
 
 // In-kernel stamps (diagnostic build only; never in the shipped library): lane 0 of each wave records
@@ -70,18 +95,43 @@ struct Params {
 #define MAPF_STAMP(k) do { } while (0)
 #endif
 
-// per-launch arguments (passed by value); Params lives in device memory and is read through a
-// __restrict__ pointer so that its fields are scalar-loaded where they are used instead of being
-// held (and spilled) in SGPRs for the whole kernel
-struct Io {
-    const int8_t *actions;
-    float *obs, *rewards;
-    uint8_t *terminated, *truncated;
-    float *info_all;
-    uint8_t *info_agent;
-    float *final_obs;
-    const uint8_t *env_mask;
-    int auto_reset;
+// ------------------------------------------------------------------------------------------------
+// configuration policies
+// ------------------------------------------------------------------------------------------------
+constexpr int obs_len_of(int sr, uint32_t flags) {
+    return (2 * sr + 1) * (2 * sr + 1) + 2 + ((flags & MAPF_FLAG_GOAL_DISTANCE) ? 1 : 0) +
+           ((flags & MAPF_FLAG_BLOCKING_PRESSURE) ? 1 : 0) + ((flags & MAPF_FLAG_ACTION_MASK) ? 5 : 0);
+}
+
+struct KRuntime {
+    static constexpr bool kFixed = false;
+    __device__ static __forceinline__ int N(const Params &p) { return p.N; }
+    __device__ static __forceinline__ int sr(const Params &p) { return p.sr; }
+    __device__ static __forceinline__ int V(const Params &p) { return p.V; }
+    __device__ static __forceinline__ int L(const Params &p) { return p.L; }
+    __device__ static __forceinline__ uint32_t flags(const Params &p) { return p.flags; }
+    __device__ static __forceinline__ int dw(const Params &p) { return p.dw; }
+    __device__ static __forceinline__ int lw(const Params &p) { return p.lw; }
+    __device__ static __forceinline__ int hs(const Params &p) { return p.hs; }
+    __device__ static __forceinline__ int nearby(const Params &p) { return p.nearby; }
+    __device__ static __forceinline__ int min_nbrs(const Params &p) { return p.min_nbrs; }
+    __device__ static __forceinline__ int ring_stride(const Params &p) { return p.ring_stride; }
+};
+
+template <int N_, int SR_, uint32_t FLAGS_, int DW_, int LW_, int NEARBY_, int MINN_>
+struct KFixed {
+    static constexpr bool kFixed = true;
+    __device__ static __forceinline__ int N(const Params &) { return N_; }
+    __device__ static __forceinline__ int sr(const Params &) { return SR_; }
+    __device__ static __forceinline__ int V(const Params &) { return 2 * SR_ + 1; }
+    __device__ static __forceinline__ int L(const Params &) { return obs_len_of(SR_, FLAGS_); }
+    __device__ static __forceinline__ uint32_t flags(const Params &) { return FLAGS_; }
+    __device__ static __forceinline__ int dw(const Params &) { return DW_; }
+    __device__ static __forceinline__ int lw(const Params &) { return LW_; }
+    __device__ static __forceinline__ int hs(const Params &) { return DW_ > LW_ ? DW_ : LW_; }
+    __device__ static __forceinline__ int nearby(const Params &) { return NEARBY_; }
+    __device__ static __forceinline__ int min_nbrs(const Params &) { return MINN_; }
+    __device__ static __forceinline__ int ring_stride(const Params &) { return (LW_ + 7) & ~7; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -132,7 +182,8 @@ template <>
 struct WMask<32> {
     uint32_t lo;
     __device__ __forceinline__ void clear() { lo = 0; }
-    __device__ __forceinline__ void set_if(bool c, int b) { lo |= (c ? 1u : 0u) << b; }
+    __device__ __forceinline__ void set_if(bool c, int b) { lo |= c ? (1u << (b & 31)) : 0u; }
+    __device__ __forceinline__ void clear_bit(int b) { lo &= ~(1u << b); }
     __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1u; }
     __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= w << shift; }
     __device__ __forceinline__ uint32_t nib(int t0) const { return (lo >> t0) & 15u; }
@@ -143,7 +194,8 @@ template <>
 struct WMask<64> {
     uint64_t lo;
     __device__ __forceinline__ void clear() { lo = 0; }
-    __device__ __forceinline__ void set_if(bool c, int b) { lo |= (c ? 1ull : 0ull) << b; }
+    __device__ __forceinline__ void set_if(bool c, int b) { lo |= c ? (1ull << (b & 63)) : 0ull; }
+    __device__ __forceinline__ void clear_bit(int b) { lo &= ~(1ull << b); }
     __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1ull; }
     __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= (uint64_t)w << shift; }
     __device__ __forceinline__ uint32_t nib(int t0) const { return (uint32_t)(lo >> t0) & 15u; }
@@ -156,7 +208,10 @@ struct WMask<128> {
     __device__ __forceinline__ void clear() { lo = hi = 0; }
     __device__ __forceinline__ void set_if(bool c, int b) {
         const uint64_t v = c ? 1ull : 0ull;
-        if (b < 64) lo |= v << b; else hi |= v << (b - 64);
+        if (b < 64) lo |= v << (b & 63); else hi |= v << ((b - 64) & 63);
+    }
+    __device__ __forceinline__ void clear_bit(int b) {
+        if (b < 64) lo &= ~(1ull << b); else hi &= ~(1ull << (b - 64));
     }
     __device__ __forceinline__ bool get(int b) const { return b < 64 ? ((lo >> b) & 1ull) : ((hi >> (b - 64)) & 1ull); }
     __device__ __forceinline__ void or_row(uint32_t w, int shift) {
@@ -187,8 +242,8 @@ __device__ __forceinline__ uint32_t row_window(uint64_t ext, int c0, int V) {
     return (uint32_t)w & ((1u << V) - 1u);
 }
 
-// 4 mask bits -> 4 bytes (bit i -> byte i LSB)
-__device__ __forceinline__ uint32_t spread4(uint32_t n) { return (n * 0x00204081u) & 0x01010101u; }
+// |r - r'| + |c - c'| of two packed cells (row<<8 | col, upper half zero): one v_sad_u8
+__device__ __forceinline__ int cell_l1(uint32_t x, uint32_t y) { return (int)__builtin_amdgcn_sad_u8(x, y, 0u); }
 
 // ------------------------------------------------------------------------------------------------
 // NumPy Generator(PCG64) on device (numpy 2.2.6: pcg64.h, distributions.c, _generator.pyx)
@@ -249,9 +304,9 @@ struct Lane {
     uint64_t moved, failed, progress;
 };
 
-__device__ __forceinline__ void load_lane(const Params &p, int env, int a, bool is_agent, Lane &st) {
+__device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
     if (is_agent) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(p.agents + (size_t)env * p.N + a);
+        const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
         uint4 q0 = rp[0], q1 = rp[1];
         st.pos = q0.x & 0xFFFFu;
         st.goal = q0.x >> 16;
@@ -262,15 +317,15 @@ __device__ __forceinline__ void load_lane(const Params &p, int env, int a, bool 
         st.progress = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
     } else {
         st.pos = kIdleCell;
-        st.goal = 0xFFFDu;
+        st.goal = kIdleGoal;
         st.start = kIdleCell;
         st.flags = 0;
         st.moved = st.failed = st.progress = 0;
     }
 }
 
-__device__ __forceinline__ void store_lane(const Params &p, int env, int a, const Lane &st) {
-    uint4 *rp = reinterpret_cast<uint4 *>(p.agents + (size_t)env * p.N + a);
+__device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
+    uint4 *rp = reinterpret_cast<uint4 *>(rec);
     uint4 q0, q1;
     q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
     q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
@@ -284,24 +339,24 @@ __device__ __forceinline__ void store_lane(const Params &p, int env, int a, cons
     rp[1] = q1;
 }
 
-__device__ __forceinline__ void load_scal(const Params &p, int env, int *sc) {
-    const int4 *sp = reinterpret_cast<const int4 *>(p.scal + (size_t)env * kScalInts);
+__device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
+    const int4 *sp = reinterpret_cast<const int4 *>(scal + (size_t)env * kScalInts);
     int4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
     sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w;
     sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
     sc[8] = s2.x; sc[9] = s2.y; sc[10] = s2.z; sc[11] = s2.w;
 }
-__device__ __forceinline__ void store_scal(const Params &p, int env, const int *sc) {
-    int4 *sp = reinterpret_cast<int4 *>(p.scal + (size_t)env * kScalInts);
+__device__ __forceinline__ void store_scal(int *scal, int env, const int *sc) {
+    int4 *sp = reinterpret_cast<int4 *>(scal + (size_t)env * kScalInts);
     sp[0] = make_int4(sc[0], sc[1], sc[2], sc[3]);
     sp[1] = make_int4(sc[4], sc[5], sc[6], sc[7]);
     sp[2] = make_int4(sc[8], sc[9], sc[10], sc[11]);
 }
 
-template <int LPE>
-__device__ __forceinline__ void load_rows_to_lds(const Params &p, uint64_t *lrows, int lane, int env0, int ngroups) {
-    const int total = ngroups * p.H;
-    const uint64_t *src = p.grid_rows + (size_t)env0 * p.H;
+__device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
+                                                 int ngroups) {
+    const int total = ngroups * H;
+    const uint64_t *src = grid_rows + (size_t)env0 * H;
     for (int k0 = 0; k0 < total; k0 += 256) {
         uint64_t t[4];
 #pragma unroll
@@ -334,32 +389,35 @@ __device__ __forceinline__ void raise_error(const Params &p, int code, int env, 
 // Outcomes depend on lower indices only, so they resolve in rounds of two ballots; almost every
 // agent has no dependency at all and the loop ends after one round.
 // ------------------------------------------------------------------------------------------------
-template <int LPE>
+template <class K, int LPE>
 __device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, int lane, int a, uint32_t old,
                                                   uint32_t tgt) {
     constexpr int C = LPE < 8 ? LPE : 8;
-    tabg[a] = make_uint2(old, tgt);
+    const int N = K::N(p);
+    tabg[a] = make_uint2(old, tgt);  // idle lanes publish {kIdleCell, kNoCell}: they match nothing
     wave_lds_sync();
     int occ_by = -1;
-    uint64_t cont = 0;
+    uint32_t cont_lo = 0, cont_hi = 0;  // lower-index contenders for my target
     const bool want = tgt != kNoCell;
-    for (int j0 = 0; j0 < p.N; j0 += C) {
+    for (int j0 = 0; j0 < N; j0 += C) {
         uint2 e[C];
 #pragma unroll
         for (int u = 0; u < C; u++) e[u] = tabg[j0 + u];
 #pragma unroll
         for (int u = 0; u < C; u++) {
             const int j = j0 + u;
-            const bool vj = j < p.N;
-            if (vj && e[u].x == tgt) occ_by = j;  // positions are unique: at most one occupant
-            if (vj && j < a && want && e[u].y == tgt) cont |= 1ull << j;
+            if (e[u].x == tgt) occ_by = j;  // positions are unique: at most one occupant
+            const bool c = want && j < a && e[u].y == tgt;
+            if (LPE <= 32 || j < 32) cont_lo |= c ? (1u << (j & 31)) : 0u;
+            else cont_hi |= c ? (1u << (j & 31)) : 0u;
         }
     }
+    const uint64_t cont = (uint64_t)cont_lo | ((uint64_t)cont_hi << 32);
     const bool occ_low = occ_by >= 0 && occ_by < a;
     const uint64_t dep = cont | (occ_low ? (1ull << occ_by) : 0ull);
     bool resolved = !want, moved = false;
     uint64_t R = gballot<LPE>(resolved, lane), M = 0;
-    for (int it = 0; it <= p.N; it++) {
+    for (int it = 0; it <= N; it++) {
         if (__all(resolved)) break;
         if (!resolved && (dep & ~R) == 0) {
             const bool blocked = (occ_by > a) || (occ_low && !((M >> occ_by) & 1ull)) || (cont & M) != 0;
@@ -369,7 +427,7 @@ __device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, 
         R = gballot<LPE>(resolved, lane);
         M = gballot<LPE>(moved, lane);
     }
-    wave_lds_sync();  // table may be rewritten after this point
+    wave_lds_sync();  // the table region is rewritten after this point
     return moved ? tgt : old;
 }
 
@@ -377,7 +435,8 @@ __device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, 
 // observation of every agent lane -> LDS staging row (MA-env:707-747 get_obs, :749-773 mask,
 // :306-335 flatten), fused with the other all-pairs work of a step when FULL: neighbour sets of
 // the lock detector (MA-env:389-398), intent blocking (:608-623), coincidence penalty (:658-666).
-//   table entry of agent j: x = old | new<<16,  y = goal | action<<16 | reached<<19 | (delta+256)<<20
+// Pair-table entry of agent j:
+//   x = old | new<<16      y = goal | reached<<16 | (delta+256)<<17      z = intended cell (+1,+1) or ~0
 // final_state: everybody at their new cell (reset, or after a lifelong respawn MA-env:565-575);
 // otherwise agent i sees agents <= i at their new cell and agents > i at their old one (MA-env:528).
 // ------------------------------------------------------------------------------------------------
@@ -385,21 +444,23 @@ struct PairOut {
     uint64_t nbr;   // agents within lock_nearby_manhattan (final positions), self excluded
     int sum_delta;  // sum over {self} U nbr of (distance at window start - distance now)
     bool blocks;    // some not-yet-reached agent intended to enter my cell
-    int coincide;   // agents sharing my cell (0 by invariant)
+    int coincide;   // other agents sharing my cell (0 by invariant)
 };
 
-template <int LPE, int MW, bool FULL>
-__device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, const uint2 *tabg, float *srow,
+template <class K, int LPE, int MW, bool FULL>
+__device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, const uint4 *tabg, float *srow,
                                         bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
                                         bool pressure, int my_delta, PairOut &po) {
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
     constexpr int C = LPE < 8 ? LPE : 8;
-    const int V = p.V, sr = p.sr;
+    const int N = K::N(p), V = K::V(p), sr = K::sr(p);
+    const uint32_t flags = K::flags(p);
     const int myr = (int)(cur >> 8), myc = (int)(cur & 255u);
     const int r0 = myr - sr, c0 = myc - sr;
+    const uint32_t mycell1 = cur + 0x0101u;  // (row+1)<<8 | (col+1): the encoding of intended cells
 
-    WMask<MW> obst, agm, own, oth;
-    obst.clear(); agm.clear(); own.clear(); oth.clear();
+    WMask<MW> obst, agm, goals;
+    obst.clear(); agm.clear(); goals.clear();
 
     uint64_t rows[MAXV];
 #pragma unroll
@@ -410,40 +471,40 @@ __device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, 
         rows[d] = in ? v : ~0ull;
     }
 
-    po.nbr = 0;
-    po.sum_delta = my_delta;
-    po.blocks = false;
-    po.coincide = 0;
-    for (int j0 = 0; j0 < p.N; j0 += C) {
-        uint2 e[C];
+    uint32_t nbr_lo = 0, nbr_hi = 0;
+    int sum_biased = 0, same_cell = 0;
+    bool blocks = false;
+    for (int j0 = 0; j0 < N; j0 += C) {
+        uint4 e[C];
 #pragma unroll
         for (int u = 0; u < C; u++) e[u] = tabg[j0 + u];
 #pragma unroll
         for (int u = 0; u < C; u++) {
             const int j = j0 + u;
-            const bool vj = j < p.N;
             const uint32_t Aj = e[u].x, Bj = e[u].y;
-            const uint32_t oldj = Aj & 0xFFFFu, newj = Aj >> 16;
-            const uint32_t pj = (final_state || j <= a) ? newj : oldj;
+            const uint32_t newj = Aj >> 16;
+            const uint32_t pj = (final_state || j <= a) ? newj : (Aj & 0xFFFFu);
+            // occupancy (self included: it sets the centre bit, cleared below) and goals (own included)
             const int pr = (int)(pj >> 8) - r0, pc = (int)(pj & 255u) - c0;
-            agm.set_if(vj && j != a && (unsigned)pr < (unsigned)V && (unsigned)pc < (unsigned)V, pr * V + pc);
+            agm.set_if(max((unsigned)pr, (unsigned)pc) < (unsigned)V, __mul24(pr, V) + pc);
             const int gr = (int)((Bj >> 8) & 255u) - r0, gc = (int)(Bj & 255u) - c0;
-            const bool gin = vj && (unsigned)gr < (unsigned)V && (unsigned)gc < (unsigned)V;
-            own.set_if(gin && j == a, gr * V + gc);
-            oth.set_if(gin && j != a, gr * V + gc);
+            goals.set_if(max((unsigned)gr, (unsigned)gc) < (unsigned)V, __mul24(gr, V) + gc);
             if (FULL) {
-                const int d = abs((int)(newj >> 8) - myr) + abs((int)(newj & 255u) - myc);
-                if (vj && d > 0 && d <= p.nearby) {
-                    po.nbr |= 1ull << j;
-                    po.sum_delta += (int)((Bj >> 20) & 1023u) - 256;
-                }
-                const int actj = (int)((Bj >> 16) & 7u);
-                const int ir = (int)(oldj >> 8) + ((actj == 1) ? -1 : ((actj == 3) ? 1 : 0));
-                const int ic = (int)(oldj & 255u) + ((actj == 2) ? 1 : ((actj == 4) ? -1 : 0));
-                if (vj && j != a && !((Bj >> 19) & 1u) && ir == myr && ic == myc) po.blocks = true;
-                if (vj && j != a && newj == cur) po.coincide += 1;
+                const int d = cell_l1(newj, cur);
+                const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);  // 0 < d <= nearby
+                if (LPE <= 32 || j < 32) nbr_lo |= isn ? (1u << (j & 31)) : 0u;
+                else nbr_hi |= isn ? (1u << (j & 31)) : 0u;
+                sum_biased += isn ? (int)((Bj >> 17) & 1023u) : 0;
+                blocks |= e[u].z == mycell1;
+                same_cell += (newj == cur) ? 1 : 0;
             }
         }
+    }
+    if (FULL) {
+        po.nbr = (uint64_t)nbr_lo | ((uint64_t)nbr_hi << 32);
+        po.sum_delta = my_delta + sum_biased - 256 * (__popc(nbr_lo) + __popc(nbr_hi));
+        po.blocks = blocks;
+        po.coincide = same_cell - 1;  // the loop counted me as well
     }
     if (!is_agent) return;
 
@@ -451,35 +512,47 @@ __device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, 
     for (int d = 0; d < MAXV; d++) {
         if (d < V) obst.or_row(row_window(rows[d], c0, V), d * V);
     }
+    const int ctr = sr * V + sr;
+    agm.clear_bit(ctr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
+    WMask<MW> own;
+    own.clear();
+    {
+        const int gr = (int)((goal >> 8) & 255u) - r0, gc = (int)(goal & 255u) - c0;
+        own.set_if(max((unsigned)gr, (unsigned)gc) < (unsigned)V, __mul24(gr, V) + gc);
+    }
 
     // cell code priority: obstacle / out-of-bounds 1 > other agent 2 > own goal 3 > other goal 4 > empty 0,
     // as three bit planes; four cells are converted per round (bit spread + byte->float converts)
     const WMask<MW> oa = obst | agm;
     const WMask<MW> g3 = own.andnot(oa);
-    const WMask<MW> g4 = oth.andnot(oa | own);
+    const WMask<MW> g4 = goals.andnot(oa | own);
     const WMask<MW> bit0 = obst | g3;
     const WMask<MW> bit1 = agm.andnot(obst) | g3;
     const int VV = V * V;
-    for (int t0 = 0; t0 < VV; t0 += 4) {
-        const uint32_t by = spread4(bit0.nib(t0)) | (spread4(bit1.nib(t0)) << 1) | (spread4(g4.nib(t0)) << 2);
-        srow[t0] = (float)(by & 0xFFu);
-        if (t0 + 1 < VV) srow[t0 + 1] = (float)((by >> 8) & 0xFFu);
-        if (t0 + 2 < VV) srow[t0 + 2] = (float)((by >> 16) & 0xFFu);
-        if (t0 + 3 < VV) srow[t0 + 3] = (float)(by >> 24);
+    constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
+#pragma unroll
+    for (int t0 = 0; t0 < MAXV * MAXV; t0 += 4) {
+        if (t0 < VV) {
+            const uint32_t by = ((bit0.nib(t0) * KS) & MS) | (((bit1.nib(t0) * KS) & MS) << 1) |
+                                (((g4.nib(t0) * KS) & MS) << 2);
+            srow[t0] = (float)(by & 0xFFu);
+            if (t0 + 1 < VV) srow[t0 + 1] = (float)((by >> 8) & 0xFFu);
+            if (t0 + 2 < VV) srow[t0 + 2] = (float)((by >> 16) & 0xFFu);
+            if (t0 + 3 < VV) srow[t0 + 3] = (float)(by >> 24);
+        }
     }
     float *q = srow + VV;
     float gd_r = (float)((int)((goal >> 8) & 255u) - myr);
     float gd_c = (float)((int)(goal & 255u) - myc);
-    if (p.flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) {
+    if (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) {
         gd_r = gd_r / p.den_r;
         gd_c = gd_c / p.den_c;
     }
     *q++ = gd_r;
     *q++ = gd_c;
-    if (p.flags & MAPF_FLAG_GOAL_DISTANCE) *q++ = fabsf(gd_r) + fabsf(gd_c);
-    if (p.flags & MAPF_FLAG_BLOCKING_PRESSURE) *q++ = pressure ? 1.0f : 0.0f;
-    if (p.flags & MAPF_FLAG_ACTION_MASK) {
-        const int ctr = sr * V + sr;
+    if (flags & MAPF_FLAG_GOAL_DISTANCE) *q++ = fabsf(gd_r) + fabsf(gd_c);
+    if (flags & MAPF_FLAG_BLOCKING_PRESSURE) *q++ = pressure ? 1.0f : 0.0f;
+    if (flags & MAPF_FLAG_ACTION_MASK) {
         bool up = false, rt = false, dn = false, lf = false;
         if (sr > 0) {
             up = !oa.get(ctr - V);
@@ -498,10 +571,11 @@ __device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, 
 // copy the wave's staged observations to global memory.  sel (per lane, uniform inside a group):
 // 0 -> io.obs, 1 -> io.final_obs, 2 -> skip.  Flat 16-byte stores when every valid group goes to
 // the same tensor, otherwise one contiguous run per group.
-template <int LPE>
-__device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const float *stage, int lane, int env0, int ngroups, int sel) {
+template <class K, int LPE>
+__device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const float *stage, int lane, int env0,
+                                          int ngroups, int sel) {
     constexpr int G = 64 / LPE;
-    const int NL = p.N * p.L;
+    const int NL = K::N(p) * K::L(p);
     const uint64_t valid = __ballot((lane / LPE) < ngroups);
     const uint64_t m0 = __ballot((lane / LPE) < ngroups && sel == 0);
     const uint64_t m1 = __ballot((lane / LPE) < ngroups && sel == 1);
@@ -532,35 +606,41 @@ __device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const f
     }
 }
 
+// pair-table entry for a static state (reset / observe kernels): nothing moves, nobody intends anything
+__device__ __forceinline__ uint4 static_entry(uint32_t pos, uint32_t goal) {
+    return make_uint4(pos | (pos << 16), goal | (256u << 17), 0xFFFFFFFFu, 0u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // reset() of the groups with do_reset set (MA-env:440-472).  Group-uniform inputs; called under a
 // wave-uniform branch.  Updates lane state + scalars; stages the reset observation when want_obs.
 // ------------------------------------------------------------------------------------------------
-template <int LPE, int MW>
-__device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lrows, uint2 *tab, float *stage,
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lrows, uint4 *tab, float *stage,
                                              int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
                                              bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs) {
-    if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) {
+    const int N = K::N(p);
+    if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
         // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False)
         int16_t *hs = scratch + grp * p.scratch_i16;
         int16_t *out = hs + p.hash_cap;
         if (do_reset && a == 0) {
             Pcg g;
             pcg_load(g, p.rng + (size_t)env * 6);
-            const int mask = p.hash_cap - 1, size = 2 * p.N, pop = p.n_free[env];
-            for (int k = 0; k < p.hash_cap; k++) hs[k] = -1;
+            const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
+            for (int k = 0; k < hash_cap; k++) hs[k] = -1;
             for (int j = pop - size; j < pop; j++) {  // Floyd
                 int val = (int)pcg_bounded(g, (uint32_t)j);
                 int loc = val & mask;
                 // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
                 // probe counters only make termination structural
-                for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < p.hash_cap; pr++) loc = (loc + 1) & mask;
+                for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
                 if (hs[loc] == -1) {
                     hs[loc] = (int16_t)val;
                     out[j - pop + size] = (int16_t)val;
                 } else {
                     loc = j & mask;
-                    for (int pr = 0; hs[loc] != -1 && pr < p.hash_cap; pr++) loc = (loc + 1) & mask;
+                    for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
                     hs[loc] = (int16_t)j;
                     out[j - pop + size] = (int16_t)j;
                 }
@@ -577,7 +657,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lr
         if (do_reset && is_agent) {
             const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
             st.start = fc[out[a]];
-            st.goal = fc[out[p.N + a]];
+            st.goal = fc[out[N + a]];
         }
         wave_lds_sync();
     }
@@ -596,12 +676,12 @@ __device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lr
         sc[MAPF_CTR_LOCK_STATE_PREV] = 0;
     }
     if (want_obs) {
-        uint2 *tabg = tab + grp * LPE;
-        tabg[a] = make_uint2(st.pos | (st.pos << 16), st.goal);
+        uint4 *tabg = tab + grp * LPE;
+        tabg[a] = static_entry(st.pos, st.goal);
         wave_lds_sync();
         PairOut po;
-        observe<LPE, MW, false>(p, lrows + grp * p.H, tabg, stage + (size_t)(grp * p.N + a) * p.L, is_agent && do_reset,
-                                a, st.pos, st.goal, true, false, 0, po);
+        observe<K, LPE, MW, false>(p, lrows + grp * p.H, tabg, stage + (size_t)(grp * N + a) * K::L(p),
+                                   is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
         wave_lds_sync();
     }
 }
@@ -609,14 +689,14 @@ __device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lr
 // LDS carve-up shared by the three kernels
 struct Lds {
     uint64_t *rows;
-    uint2 *tab;
+    uint4 *tab;
     float *stage;
     int16_t *scratch;
 };
 __device__ __forceinline__ Lds carve_lds(const Params &p, unsigned char *raw) {
     Lds l;
     l.rows = reinterpret_cast<uint64_t *>(raw);
-    l.tab = reinterpret_cast<uint2 *>(raw + p.lds_tab_off);
+    l.tab = reinterpret_cast<uint4 *>(raw + p.lds_tab_off);
     l.stage = reinterpret_cast<float *>(raw + p.lds_stage_off);
     l.scratch = reinterpret_cast<int16_t *>(raw + p.lds_scratch_off);
     return l;
@@ -625,7 +705,7 @@ __device__ __forceinline__ Lds carve_lds(const Params &p, unsigned char *raw) {
 // ------------------------------------------------------------------------------------------------
 // reset kernel
 // ------------------------------------------------------------------------------------------------
-template <int LPE, int MW>
+template <class K, int LPE, int MW>
 __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, const Io io) {
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
@@ -636,22 +716,23 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     const int ngroups = min(G, p.B - env0);
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : p.B - 1;
-    const bool is_agent = env_ok && a < p.N;
+    const int N = K::N(p);
+    const bool is_agent = env_ok && a < N;
 
-    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    load_rows_to_lds(io.grid_rows, p.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(p, env, a, is_agent, st);
+    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     int sc[12];
-    load_scal(p, env, sc);
+    load_scal(io.scal, env, sc);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
 
-    reset_groups<LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
-                          io.obs != nullptr);
-    if (io.obs) flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
+    reset_groups<K, LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
+                             io.obs != nullptr);
+    if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     if (do_reset) {
-        if (is_agent) store_lane(p, env, a, st);
-        if (a == 0) store_scal(p, env, sc);
+        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (a == 0) store_scal(io.scal, env, sc);
     }
 }
 
@@ -660,7 +741,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
 // What the reference computes when get_obs / _flatten_observation are called outside step()
 // (its tests do: tests/test_reference_model_multi_agent_invariants.py:76-95).
 // ------------------------------------------------------------------------------------------------
-template <int LPE, int MW>
+template <class K, int LPE, int MW>
 __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, const Io io) {
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
@@ -671,24 +752,25 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     const int ngroups = min(G, p.B - env0);
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : p.B - 1;
-    const bool is_agent = env_ok && a < p.N;
-    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    const int N = K::N(p);
+    const bool is_agent = env_ok && a < N;
+    load_rows_to_lds(io.grid_rows, p.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(p, env, a, is_agent, st);
-    uint2 *tabg = l.tab + grp * LPE;
-    tabg[a] = make_uint2(st.pos | (st.pos << 16), st.goal);
+    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    uint4 *tabg = l.tab + grp * LPE;
+    tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
     PairOut po;
-    observe<LPE, MW, false>(p, l.rows + grp * p.H, tabg, l.stage + (size_t)(grp * p.N + a) * p.L, is_agent, a, st.pos,
-                            st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
+    observe<K, LPE, MW, false>(p, l.rows + grp * p.H, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
+                               st.pos, st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
     wave_lds_sync();
-    flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
+    flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
 }
 
 // ------------------------------------------------------------------------------------------------
 // step kernel (MA-env:474-695)
 // ------------------------------------------------------------------------------------------------
-template <int LPE, int MW>
+template <class K, int LPE, int MW>
 __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
@@ -699,27 +781,30 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const int ngroups = min(G, p.B - env0);
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : p.B - 1;
-    const bool is_agent = env_ok && a < p.N;
-    const int N = p.N;
-    const bool lifelong = (p.flags & MAPF_FLAG_LIFELONG) != 0;
-    const bool lock_on = (p.flags & MAPF_FLAG_LOCK_METRICS) != 0;
-    uint2 *tabg = l.tab + grp * LPE;
-    const uint64_t *myrows = l.rows + grp * p.H;
+    const int N = K::N(p), H = p.H, W = p.W;
+    const uint32_t flags = K::flags(p);
+    const bool is_agent = env_ok && a < N;
+    const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0;
+    const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
+    const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
+    uint4 *tabg = l.tab + grp * LPE;
+    const uint64_t *myrows = l.rows + grp * H;
+    AgentRec *rec = io.agents + (size_t)env * N + a;
 
     MAPF_STAMP(0);
     // ---- loads: obstacle rows -> LDS, agent record, env scalars, action, distance ring; all in flight together
-    load_rows_to_lds<LPE>(p, l.rows, lane, env0, ngroups);
+    load_rows_to_lds(io.grid_rows, H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(p, env, a, is_agent, st);
+    load_lane(rec, is_agent, st);
     int sc[12];
-    load_scal(p, env, sc);
+    load_scal(io.scal, env, sc);
     int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
-    const bool ring_pre = lock_on && p.ring_stride <= 16;  // whole per-agent ring fits two 16-byte loads
-    int16_t *ring = p.dist_ring + ((size_t)env * N + a) * p.ring_stride;
+    const bool ring_pre = lock_on && ring_stride <= 16;  // whole per-agent ring fits two 16-byte loads
+    int16_t *ring = io.dist_ring + ((size_t)env * N + a) * ring_stride;
     uint4 rq0 = make_uint4(0, 0, 0, 0), rq1 = make_uint4(0, 0, 0, 0);
     if (ring_pre && is_agent) {
         rq0 = reinterpret_cast<const uint4 *>(ring)[0];
-        if (p.ring_stride > 8) rq1 = reinterpret_cast<const uint4 *>(ring)[1];
+        if (ring_stride > 8) rq1 = reinterpret_cast<const uint4 *>(ring)[1];
     }
     wave_lds_sync();
 #ifdef MAPF_STAMPS
@@ -745,12 +830,14 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
     const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
     const int tr = r_old + dr, tc = c_old + dc;
-    const bool inb = tr >= 0 && tr < p.H && tc >= 0 && tc < p.W;
+    const bool inb = tr >= 0 && tr < H && tc >= 0 && tc < W;
     const uint64_t trow = (live && inb) ? myrows[tr] : ~0ull;
     const bool want = live && act != 0 && inb && !((trow >> tc) & 1ull);
     const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    // intended_next (MA-env:514-515) in the (+1,+1) encoding; may lie outside the grid
+    const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
     uint32_t cur = old;
-    if (__any(want)) cur = resolve_moves<LPE>(p, tabg, lane, a, old, tgt);
+    if (__any(want)) cur = resolve_moves<K, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
     const bool moved = cur != old;
     MAPF_STAMP(2);
 
@@ -769,7 +856,6 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
             reward += 0.5f;
             grs = true;
         }
-        sc[MAPF_CTR_GOALS_REACHED_TOTAL] += __popcll(gballot<LPE>(grs, lane));
     } else {
         const uint64_t arr_wave = __ballot(on_goal);
         if (arr_wave) {  // wave-uniform, rare
@@ -787,8 +873,8 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
                 // occupied cells at time i; goals of everybody else (own old goal is released first, MA-env:286-288)
                 const uint32_t P = is_agent ? ((a <= i) ? cur : old) : kIdleCell;
                 const bool Gact = is_agent && a != i;
-                const int rankP = is_agent ? (int)frank[(P >> 8) * p.W + (P & 255u)] : 0x7FFFFFFF;
-                const int rankG = Gact ? (int)frank[(st.goal >> 8) * p.W + (st.goal & 255u)] : 0x7FFFFFFF;
+                const int rankP = is_agent ? (int)frank[(P >> 8) * W + (P & 255u)] : 0x7FFFFFFF;
+                const int rankG = Gact ? (int)frank[(st.goal >> 8) * W + (st.goal & 255u)] : 0x7FFFFFFF;
                 bool dup = false;  // my goal cell is also occupied -> count it once
                 for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(P, q) == st.goal);
                 dup = dup && Gact;
@@ -822,9 +908,10 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
                 reached = false;
                 on_goal = false;  // reached_goal[i] = False after the respawn
             }
-            sc[MAPF_CTR_GOALS_REACHED_TOTAL] += __popcll(garr);
         }
     }
+    const int goals_step = __popcll(gballot<LPE>(grs, lane));
+    sc[MAPF_CTR_GOALS_REACHED_TOTAL] += goals_step;  // _episode_goals_reached_total MA-env:550,563
 
     // ---- everything below is skipped by the reference when the ValueError fired; such groups keep
     //      only the mutations made before the exception ----------------------------------------------
@@ -834,26 +921,25 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const uint64_t h_moved = st.moved, h_failed = st.failed, h_progress = st.progress;
 
     // lock flags (MA-env:581-594) and distance ring
-    const int gr_ = (int)((st.goal >> 8) & 255u), gc_ = (int)(st.goal & 255u);
-    const int r_new = (int)(cur >> 8), c_new = (int)(cur & 255u);
     const bool cur_on_goal = is_agent && cur == st.goal;
     const bool prev_on_goal = !lifelong && old == st.goal;
     const bool progress = lifelong ? grs : (!prev_on_goal && cur_on_goal);
     const bool failed = act != 0 && !moved;
-    const int dist = abs(gr_ - r_new) + abs(gc_ - c_new);
+    const int dist = cell_l1(cur, st.goal);
     int delta = 0;
     bool dl_ok = false, ll_ok = false;
     if (lock_on) {
         const int t = sc[MAPF_CTR_HIST_ROWS];
-        const int count = min(t + 1, p.hs);
-        dl_ok = count >= p.dw;
-        ll_ok = count >= p.lw;
+        const int count = min(t + 1, K::hs(p));
+        dl_ok = count >= dw;
+        ll_ok = count >= lw;
         st.moved = (st.moved << 1) | (moved ? 1ull : 0ull);  // _append_lock_history_step MA-env:374-387
         st.failed = (st.failed << 1) | (failed ? 1ull : 0ull);
         st.progress = (st.progress << 1) | (progress ? 1ull : 0ull);
-        const int slot_new = t % p.lw, slot_old = (t + 1) % p.lw;  // oldest row of the livelock window
+        const int slot_new = t % lw;
+        const int slot_old = (slot_new + 1 == lw) ? 0 : slot_new + 1;  // oldest row of the livelock window
         int d_old = dist;
-        if (p.lw > 1 && ll_ok) {
+        if (lw > 1 && ll_ok) {
             if (ring_pre) {
                 const int dwi = slot_old >> 1;
                 uint32_t w = rq0.x;
@@ -876,23 +962,29 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
 
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
-    tabg[a] = make_uint2(old | (cur << 16), (st.goal & 0xFFFFu) | ((uint32_t)act << 16) | ((reached ? 1u : 0u) << 19) |
-                                                ((uint32_t)(delta + 256) << 20));
+    {
+        uint4 ent;
+        ent.x = old | (cur << 16);
+        ent.y = (st.goal & 0xFFFFu) | ((reached ? 1u : 0u) << 16) | ((uint32_t)(delta + 256) << 17);
+        ent.z = (is_agent && !reached) ? intended1 : 0xFFFFFFFFu;
+        ent.w = 0u;
+        tabg[a] = ent;
+    }
     wave_lds_sync();
     MAPF_STAMP(3);
     PairOut po;
-    observe<LPE, MW, true>(p, myrows, tabg, l.stage + (size_t)(grp * N + a) * p.L, is_agent, a, cur, st.goal, reassigned,
-                           pressure_prev, delta, po);
+    observe<K, LPE, MW, true>(p, myrows, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a, cur, st.goal,
+                              reassigned, pressure_prev, delta, po);
     MAPF_STAMP(4);
     reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
 
     // lock detector (MA-env:400-438): deadlock has priority over livelock
     int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
     if (lock_on) {
-        const uint64_t mdw = p.dw >= 64 ? ~0ull : ((1ull << p.dw) - 1ull);
-        const uint64_t mlw = p.lw >= 64 ? ~0ull : ((1ull << p.lw) - 1ull);
+        const uint64_t mdw = dw >= 64 ? ~0ull : ((1ull << dw) - 1ull);
+        const uint64_t mlw = lw >= 64 ? ~0ull : ((1ull << lw) - 1ull);
         const uint64_t members = po.nbr | (1ull << a);
-        const bool focal = is_agent && !cur_on_goal && __popcll(po.nbr) >= p.min_nbrs;
+        const bool focal = is_agent && !cur_on_goal && __popcll(po.nbr) >= K::min_nbrs(p);
         const uint64_t prog_dw_nz = gballot<LPE>(is_agent && (st.progress & mdw) != 0, lane);
         const uint64_t moved_dw_nz = gballot<LPE>(is_agent && (st.moved & mdw) != 0, lane);
         const uint64_t fail_dw_nz = gballot<LPE>(is_agent && (st.failed & mdw) != 0, lane);
@@ -938,13 +1030,12 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     MAPF_STAMP(5);
     if (io.obs || io.final_obs) {
         const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-        flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, sel);
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
     }
 
     MAPF_STAMP(6);
     // ---- per-step outputs: info (MA-env:627-656), rewards, done flags --------------------------------
     {
-        const int goals_step = __popcll(gballot<LPE>(grs, lane));
         const int reached_cnt = __popcll(gballot<LPE>(is_agent && reached, lane));
         const int completed_cnt = __popcll(gballot<LPE>(is_agent && completed, lane));
         const int goals_total = lifelong ? sc[MAPF_CTR_GOALS_REACHED_TOTAL] : reached_cnt;
@@ -1005,17 +1096,32 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     if (__any(do_reset)) {
         if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
         wave_lds_sync();
-        reset_groups<LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
-                              io.obs != nullptr);
-        if (io.obs) flush_obs<LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
+        reset_groups<K, LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
+                                 sc, io.obs != nullptr);
+        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }
-    if (is_agent) store_lane(p, env, a, st);
-    if (env_ok && a == 0) store_scal(p, env, sc);
+    if (is_agent) store_lane(rec, st);
+    if (env_ok && a == 0) store_scal(io.scal, env, sc);
     MAPF_STAMP(8);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
 #endif
     MAPF_STAMP(9);
 }
+
+// ------------------------------------------------------------------------------------------------
+// compile-time specialisations of the step kernel for the BASELINE.json shapes (SURVEY 8(d) flags:
+// sensor_range 2, lock windows 8/16, nearby 2, min_neighbors 1).  X(id, N, SR, FLAGS, DW, LW, NEARBY, MINN, LPE)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kFlagsHeadline = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_ACTION_MASK |
+                                    MAPF_FLAG_BLOCKING_PRESSURE | MAPF_FLAG_LOCK_METRICS;  // L = 33
+constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_BLOCKING_PRESSURE |
+                                      MAPF_FLAG_LOCK_METRICS;  // the reference's default obs, L = 28
+#define MAPF_SPECIALIZATIONS(X)                                            \
+    X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)                              \
+    X(2, 4, 2, kFlagsHeadline, 8, 16, 2, 1, 4)                              \
+    X(3, 64, 2, (kFlagsHeadline | MAPF_FLAG_LIFELONG), 8, 16, 2, 1, 64)     \
+    X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8)                            \
+    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)
 
 }  // namespace

@@ -53,6 +53,7 @@ struct mapf_engine {
     Params p;
     int lpe = 0;
     int mask_w = 32;
+    int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     int blocks = 0;
     int lds_bytes = 0;
     bool grids_set = false;
@@ -96,19 +97,46 @@ enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP)
-        hipLaunchKernelGGL((k_step<LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+        hipLaunchKernelGGL((k_step<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     else if (kind == KIND_RESET)
-        hipLaunchKernelGGL((k_reset<LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+        hipLaunchKernelGGL((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     else
-        hipLaunchKernelGGL((k_observe<LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+        hipLaunchKernelGGL((k_observe<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     return hipGetLastError();
 }
 
+// the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
+int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
+    if (c.flags & MAPF_FLAG_GENERIC_KERNEL) return 0;
+#define MAPF_MATCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                            \
+    if (c.num_agents == N_ && c.sensor_range == SR_ && c.flags == (uint32_t)(FLAGS_) &&                             \
+        c.deadlock_window_steps == DW_ && c.livelock_window_steps == LW_ && nearby_clamped == NEARBY_ &&           \
+        c.lock_min_neighbors == MINN_ && lpe == LPE_)                                                              \
+        return ID;
+    MAPF_SPECIALIZATIONS(MAPF_MATCH)
+#undef MAPF_MATCH
+    return 0;
+}
+
+hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream_t s) {
+    switch (e->special) {
+#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((k_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),        \
+                           dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);                            \
+        return hipGetLastError();
+        MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
+#undef MAPF_LAUNCH
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
+    if (kind == KIND_STEP && e->special) return launch_specialized_step(e, io, s);
 #define MAPF_CASE(L)                                                       \
     case L:                                                                \
-        if (e->mask_w == 32) return launch_kind<L, 32>(kind, e, io, s);     \
-        if (e->mask_w == 64) return launch_kind<L, 64>(kind, e, io, s);     \
+        if (e->mask_w == 32) return launch_kind<L, 32>(kind, e, io, s);    \
+        if (e->mask_w == 64) return launch_kind<L, 64>(kind, e, io, s);    \
         return launch_kind<L, 128>(kind, e, io, s);
     switch (e->lpe) {
         MAPF_CASE(4)
@@ -148,6 +176,9 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (c.deadlock_window_steps < 1) c.deadlock_window_steps = 1;
     if (c.livelock_window_steps < 1) c.livelock_window_steps = 1;
     if (c.lock_nearby_manhattan < 1) c.lock_nearby_manhattan = 1;
+    // two cells of a <= 64x64 grid are at most 126 apart, so a larger radius means the same thing; the cap
+    // keeps the idle-lane sentinel cell (row 255) outside every neighbourhood
+    if (c.lock_nearby_manhattan > 126) c.lock_nearby_manhattan = 126;
     if (c.lock_min_neighbors < 1) c.lock_min_neighbors = 1;
     if (c.num_envs < 1) return fail(nullptr, MAPF_ERR_CONFIG, "num_envs must be >= 1");
     if (c.height < 1 || c.width < 1 || c.height > MAPF_MAX_DIM || c.width > MAPF_MAX_DIM)
@@ -180,7 +211,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.V = 2 * c.sensor_range + 1;
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
-    p.flags = c.flags;
+    p.flags = c.flags & ~MAPF_FLAG_GENERIC_KERNEL;
+    e->special = match_specialization(c, lpe, c.lock_nearby_manhattan);
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
     p.nearby = c.lock_nearby_manhattan;
@@ -204,7 +236,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.scratch_i16 = (p.hash_cap + 2 * N + 1) & ~1;
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * H * 8) + 15) & ~15;
-    const int tab_bytes = 64 * 8;  // one 8-byte entry per lane
+    const int tab_bytes = 64 * 16;  // one 16-byte entry per lane
     const int stage_bytes = ((G * N * p.L * 4) + 15) & ~15;
     const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
     p.lds_tab_off = rows_bytes;
@@ -246,11 +278,7 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMemset(e->d_ring, 0, BN * p.ring_stride * sizeof(int16_t)));
     HIP_TRY(e, hipMemset(e->d_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMemset(e->d_err, 0, 4 * sizeof(int)));
-    p.agents = e->d_agents;
-    p.scal = e->d_scal;
-    p.dist_ring = e->d_ring;
     p.rng = e->d_rng;
-    p.grid_rows = e->d_rows;
     p.free_cells = e->d_free_cells;
     p.free_rank = e->d_free_rank;
     p.n_free = e->d_n_free;
@@ -435,6 +463,10 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_reset");
     Io io;
     memset(&io, 0, sizeof io);
+    io.agents = e->d_agents;
+    io.scal = e->d_scal;
+    io.dist_ring = e->d_ring;
+    io.grid_rows = e->d_rows;
     io.env_mask = env_mask;
     io.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -448,6 +480,10 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step");
     Io io;
     memset(&io, 0, sizeof io);
+    io.agents = e->d_agents;
+    io.scal = e->d_scal;
+    io.dist_ring = e->d_ring;
+    io.grid_rows = e->d_rows;
     io.actions = actions;
     io.obs = obs;
     io.rewards = rewards;
@@ -467,6 +503,10 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_observe");
     Io io;
     memset(&io, 0, sizeof io);
+    io.agents = e->d_agents;
+    io.scal = e->d_scal;
+    io.dist_ring = e->d_ring;
+    io.grid_rows = e->d_rows;
     io.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
@@ -517,7 +557,7 @@ int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *
     if (threads) *threads = 64;
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (lanes_per_env) *lanes_per_env = e->lpe;
-    return MAPF_OK;
+    return e->special;  /* >= 0: id of the compile-time specialisation in use (0 = runtime-config kernel) */
 }
 
 }  // extern "C"

@@ -11,6 +11,8 @@ extension keys:
     rng_words       uint64 [B,6] explicit PCG64 states (overrides seeds)
     fixed_starts / fixed_goals   int16 [B,N,2] or [N,2] for ``deterministic`` on synthetic grids
     lanes_per_env   engine tuning knob (0 = auto)
+    force_generic_kernel   engine knob: use the runtime-config step kernel even when a compile-time
+                    specialisation (BASELINE.json shapes) matches
 
 All hot-path calls are asynchronous on the current torch stream; outputs are preallocated device
 tensors that are overwritten by the next call (clone them to keep them).
@@ -58,6 +60,8 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_LOCK_METRICS
     if cfg.get("deterministic", False):
         f |= L.FLAG_DETERMINISTIC
+    if cfg.get("force_generic_kernel", False):  # engine knob: skip the compile-time specialised step kernel
+        f |= L.FLAG_GENERIC_KERNEL
     return f
 
 
@@ -171,8 +175,9 @@ class VecReferenceModel:
 
     def launch_info(self) -> dict:
         b, t, l, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-        self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
-        return {"blocks": b.value, "threads": t.value, "lds_bytes": l.value, "lanes_per_env": p.value}
+        special = self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
+        return {"blocks": b.value, "threads": t.value, "lds_bytes": l.value, "lanes_per_env": p.value,
+                "specialized_kernel": int(special)}
 
     # ------------------------------------------------------------------------------------------
     def reset(self, env_mask: torch.Tensor | None = None) -> torch.Tensor:

@@ -60,6 +60,7 @@ extern "C" {
 #define MAPF_FLAG_LIFELONG 16u            /* lifelong_mapf [off] */
 #define MAPF_FLAG_LOCK_METRICS 32u        /* enable_lock_metrics [on] */
 #define MAPF_FLAG_DETERMINISTIC 64u       /* deterministic [off]: reset() re-places agents on fixed starts, no RNG */
+#define MAPF_FLAG_GENERIC_KERNEL 0x80000000u /* engine knob (tests): never pick a compile-time specialised step kernel */
 
 /* status codes */
 #define MAPF_OK 0
@@ -187,7 +188,8 @@ int mapf_poll_error(mapf_handle h, void *stream, int32_t *env, int32_t *agent, i
  * s_memtime stamps of the last mapf_step to host uint64 out[blocks][16]; returns the number of words. */
 int mapf_debug_stamps(mapf_handle h, uint64_t *out /* host */, int32_t max_words);
 
-/* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes) */
+/* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes).
+ * Returns >= 0: the id of the compile-time specialisation of the step kernel in use (0 = runtime-config kernel). */
 int mapf_launch_info(mapf_handle h, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env);
 
 #ifdef __cplusplus

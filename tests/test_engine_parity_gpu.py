@@ -83,6 +83,32 @@ def _vs_oracle(B, H, W, N, density, steps, cfg_extra=None, greedy=False):
                             check_state_every=25)
 
 
+def test_specialized_and_generic_kernels_are_both_exercised():
+    """The BASELINE shapes pick a compile-time specialised step kernel; force_generic_kernel must disable it."""
+    from dl_reference_models_amd import workloads as wl
+    from dl_reference_models_amd.vec_env import VecReferenceModel
+
+    for name, want in (("c3_8192x32x32_n8", 1), ("c2_1024x16x16_n4", 2), ("c5_1024x64x64_n64_lifelong", 3)):
+        cfg = wl.workload_config(name, list(range(4)))
+        assert VecReferenceModel(cfg).launch_info()["specialized_kernel"] == want
+        assert VecReferenceModel(dict(cfg, force_generic_kernel=True)).launch_info()["specialized_kernel"] == 0
+
+
+@pytest.mark.parametrize("shape", [(512, 16, 16, 4, 0.20, {}), (1024, 32, 32, 8, 0.40, {}),
+                                   (64, 64, 64, 64, 0.20, {"lifelong_mapf": True, "steps_per_episode": 256}),
+                                   (512, 32, 32, 8, 0.40, {"include_action_mask_in_obs": False})])
+def test_generic_kernel_on_baseline_shapes(shape):
+    """Same shapes as the specialised kernels, run through the runtime-config kernel."""
+    B, H, W, N, density, extra = shape
+    _vs_oracle(B, H, W, N, density, 260, dict(extra, force_generic_kernel=True))
+
+
+def test_engine_vs_oracle_reference_default_obs_layout():
+    """Reference-default observation (mask off, L = 28): specialisations 4 and 5."""
+    _vs_oracle(1024, 32, 32, 8, 0.40, 220, {"include_action_mask_in_obs": False})
+    _vs_oracle(512, 16, 16, 4, 0.20, 220, {"include_action_mask_in_obs": False})
+
+
 def test_engine_vs_oracle_c2_1024x16x16x4():
     """BASELINE config 2: 1024 vectorized 16x16 grids, 4 agents, bit-exact check vs CPU."""
     stats = _vs_oracle(1024, 16, 16, 4, 0.20, 320)
