@@ -148,17 +148,23 @@ def main():
 
     run_steps(args.warmup)
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     run_steps(args.steps)
+    ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    # HIP events on the launch stream over the timed region: device time per launch (kernel + the
+    # back-to-back boundary; graph replays leave no host gap).  This is the roofline's kernel time.
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
     env.poll_error()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- kernel duration for the roofline: event pairs around single launches on the launch stream ----
+    # ---- secondary: event pairs around single launches (includes ~2 us of event/launch overhead) ----
     samples = []
     for i in range(args.kernel_samples):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,14 +174,7 @@ def main():
         samples.append((e0, e1))
     torch.cuda.synchronize(device)
     per_launch_ms = np.array([a.elapsed_time(b) for a, b in samples], dtype=np.float64)
-    # back-to-back stream time per step (includes the inter-kernel boundary, no host gaps when graphed)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    run_steps(max(args.graph_steps, 100))
-    e1.record(stream)
-    torch.cuda.synchronize(device)
-    stream_ms_per_step = e0.elapsed_time(e1) / max(args.graph_steps, 100)
-    kernel_ms = float(np.median(per_launch_ms))
+    isolated_launch_ms = float(np.median(per_launch_ms)) if len(per_launch_ms) else None
 
     # off the timed path: optional RCCL sum of episode statistics (64-byte message, latency-bound)
     st = env.get_state()["counters"]
@@ -217,7 +216,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_step", "kernel_ms": kernel_ms, "stream_ms_per_step": stream_ms_per_step,
+            "kernel": "k_step", "kernel_ms": kernel_ms, "isolated_launch_ms": isolated_launch_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
         "episodes_finished": float(stats[0]),

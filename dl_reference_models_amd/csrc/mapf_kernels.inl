@@ -70,6 +70,10 @@ struct Io {
     int *scal;
     int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
+    // hot scalars (copies of the Params fields every launch needs before its first memory access)
+    int B, H, W, eps_floor, steps_per_episode;
+    float den_r, den_c;
+    int lds_tab_off, lds_stage_off, lds_scratch_off;
     const int8_t *actions;
     float *obs, *rewards;
     uint8_t *terminated, *truncated;
@@ -448,7 +452,7 @@ struct PairOut {
 };
 
 template <class K, int LPE, int MW, bool FULL>
-__device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, const uint4 *tabg, float *srow,
+__device__ __forceinline__ void observe(const Params &p, const Io &io, const uint64_t *lrows, const uint4 *tabg, float *srow,
                                         bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
                                         bool pressure, int my_delta, PairOut &po) {
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
@@ -466,7 +470,7 @@ __device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, 
 #pragma unroll
     for (int d = 0; d < MAXV; d++) {
         const int r = r0 + d;
-        const bool in = (d < V) && r >= 0 && r < p.H && is_agent;
+        const bool in = (d < V) && r >= 0 && r < io.H && is_agent;
         const uint64_t v = lrows[in ? r : 0];
         rows[d] = in ? v : ~0ull;
     }
@@ -545,8 +549,8 @@ __device__ __forceinline__ void observe(const Params &p, const uint64_t *lrows, 
     float gd_r = (float)((int)((goal >> 8) & 255u) - myr);
     float gd_c = (float)((int)(goal & 255u) - myc);
     if (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) {
-        gd_r = gd_r / p.den_r;
-        gd_c = gd_c / p.den_c;
+        gd_r = gd_r / io.den_r;
+        gd_c = gd_c / io.den_c;
     }
     *q++ = gd_r;
     *q++ = gd_c;
@@ -589,7 +593,18 @@ __device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const f
             const int n4 = n >> 2;
             const float4 *s4 = reinterpret_cast<const float4 *>(stage);
             float4 *d4 = reinterpret_cast<float4 *>(dst);
-            for (int k = lane; k < n4; k += 64) d4[k] = s4[k];
+            // rounds of 4 x 1 KiB: the four LDS reads are issued back to back, then the four stores
+            for (int k0 = 0; k0 < n4; k0 += 256) {
+                // unconditional (clamped) reads keep v[] in registers; only the stores are predicated
+                const float4 v0 = s4[min(k0 + lane, n4 - 1)];
+                const float4 v1 = s4[min(k0 + 64 + lane, n4 - 1)];
+                const float4 v2 = s4[min(k0 + 128 + lane, n4 - 1)];
+                const float4 v3 = s4[min(k0 + 192 + lane, n4 - 1)];
+                if (k0 + lane < n4) d4[k0 + lane] = v0;
+                if (k0 + 64 + lane < n4) d4[k0 + 64 + lane] = v1;
+                if (k0 + 128 + lane < n4) d4[k0 + 128 + lane] = v2;
+                if (k0 + 192 + lane < n4) d4[k0 + 192 + lane] = v3;
+            }
             for (int k = (n4 << 2) + lane; k < n; k += 64) dst[k] = stage[k];
         } else {
             for (int k = lane; k < n; k += 64) dst[k] = stage[k];
@@ -616,7 +631,7 @@ __device__ __forceinline__ uint4 static_entry(uint32_t pos, uint32_t goal) {
 // wave-uniform branch.  Updates lane state + scalars; stages the reset observation when want_obs.
 // ------------------------------------------------------------------------------------------------
 template <class K, int LPE, int MW>
-__device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lrows, uint4 *tab, float *stage,
+__device__ __forceinline__ void reset_groups(const Params &p, const Io &io, const uint64_t *lrows, uint4 *tab, float *stage,
                                              int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
                                              bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs) {
     const int N = K::N(p);
@@ -680,7 +695,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const uint64_t *lr
         tabg[a] = static_entry(st.pos, st.goal);
         wave_lds_sync();
         PairOut po;
-        observe<K, LPE, MW, false>(p, lrows + grp * p.H, tabg, stage + (size_t)(grp * N + a) * K::L(p),
+        observe<K, LPE, MW, false>(p, io, lrows + grp * io.H, tabg, stage + (size_t)(grp * N + a) * K::L(p),
                                    is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
         wave_lds_sync();
     }
@@ -693,12 +708,12 @@ struct Lds {
     float *stage;
     int16_t *scratch;
 };
-__device__ __forceinline__ Lds carve_lds(const Params &p, unsigned char *raw) {
+__device__ __forceinline__ Lds carve_lds(const Io &io, unsigned char *raw) {
     Lds l;
     l.rows = reinterpret_cast<uint64_t *>(raw);
-    l.tab = reinterpret_cast<uint4 *>(raw + p.lds_tab_off);
-    l.stage = reinterpret_cast<float *>(raw + p.lds_stage_off);
-    l.scratch = reinterpret_cast<int16_t *>(raw + p.lds_scratch_off);
+    l.tab = reinterpret_cast<uint4 *>(raw + io.lds_tab_off);
+    l.stage = reinterpret_cast<float *>(raw + io.lds_stage_off);
+    l.scratch = reinterpret_cast<int16_t *>(raw + io.lds_scratch_off);
     return l;
 }
 
@@ -710,16 +725,16 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds l = carve_lds(p, lds_raw);
+    const Lds l = carve_lds(io, lds_raw);
     const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G;
-    const int ngroups = min(G, p.B - env0);
+    const int ngroups = min(G, io.B - env0);
     const bool env_ok = grp < ngroups;
-    const int env = env_ok ? env0 + grp : p.B - 1;
+    const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p);
     const bool is_agent = env_ok && a < N;
 
-    load_rows_to_lds(io.grid_rows, p.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     int sc[12];
@@ -727,7 +742,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
 
-    reset_groups<K, LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
+    reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
                              io.obs != nullptr);
     if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     if (do_reset) {
@@ -746,22 +761,22 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds l = carve_lds(p, lds_raw);
+    const Lds l = carve_lds(io, lds_raw);
     const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G;
-    const int ngroups = min(G, p.B - env0);
+    const int ngroups = min(G, io.B - env0);
     const bool env_ok = grp < ngroups;
-    const int env = env_ok ? env0 + grp : p.B - 1;
+    const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p);
     const bool is_agent = env_ok && a < N;
-    load_rows_to_lds(io.grid_rows, p.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     uint4 *tabg = l.tab + grp * LPE;
     tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
     PairOut po;
-    observe<K, LPE, MW, false>(p, l.rows + grp * p.H, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
+    observe<K, LPE, MW, false>(p, io, l.rows + grp * io.H, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
                                st.pos, st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
     wave_lds_sync();
     flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
@@ -775,13 +790,13 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds l = carve_lds(p, lds_raw);
+    const Lds l = carve_lds(io, lds_raw);
     const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G;
-    const int ngroups = min(G, p.B - env0);
+    const int ngroups = min(G, io.B - env0);
     const bool env_ok = grp < ngroups;
-    const int env = env_ok ? env0 + grp : p.B - 1;
-    const int N = K::N(p), H = p.H, W = p.W;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    const int N = K::N(p), H = io.H, W = io.W;
     const uint32_t flags = K::flags(p);
     const bool is_agent = env_ok && a < N;
     const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0;
@@ -973,7 +988,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     wave_lds_sync();
     MAPF_STAMP(3);
     PairOut po;
-    observe<K, LPE, MW, true>(p, myrows, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a, cur, st.goal,
+    observe<K, LPE, MW, true>(p, io, myrows, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a, cur, st.goal,
                               reassigned, pressure_prev, delta, po);
     MAPF_STAMP(4);
     reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
@@ -993,7 +1008,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
         const bool dead_me = focal && dl_ok && (members & prog_dw_nz) == 0 && (members & moved_dw_nz) == 0 &&
                              (members & fail_dw_nz) != 0;
         const bool live_me = focal && ll_ok && (members & prog_lw_nz) == 0 && (members & moved_lw_nz) != 0 &&
-                             po.sum_delta <= p.eps_floor;
+                             po.sum_delta <= io.eps_floor;
         deadlock = gballot<LPE>(dead_me, lane) != 0;
         livelock = !deadlock && gballot<LPE>(live_me, lane) != 0;
         const int prev = sc[MAPF_CTR_LOCK_STATE_PREV];
@@ -1017,7 +1032,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     if (!lifelong && n_on_goal == N) {
         reward += 1.0f;
         term = 1;
-    } else if (sc[MAPF_CTR_STEP_COUNT] >= p.steps_per_episode) {
+    } else if (sc[MAPF_CTR_STEP_COUNT] >= io.steps_per_episode) {
         if (!lifelong && !on_goal) reward -= 1.0f;
         term = 1;
         trunc = 1;
@@ -1096,7 +1111,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     if (__any(do_reset)) {
         if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
         wave_lds_sync();
-        reset_groups<K, LPE, MW>(p, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
+        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
                                  sc, io.obs != nullptr);
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }

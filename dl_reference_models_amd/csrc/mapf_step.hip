@@ -467,6 +467,16 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     io.scal = e->d_scal;
     io.dist_ring = e->d_ring;
     io.grid_rows = e->d_rows;
+    io.B = e->p.B;
+    io.H = e->p.H;
+    io.W = e->p.W;
+    io.eps_floor = e->p.eps_floor;
+    io.steps_per_episode = e->p.steps_per_episode;
+    io.den_r = e->p.den_r;
+    io.den_c = e->p.den_c;
+    io.lds_tab_off = e->p.lds_tab_off;
+    io.lds_stage_off = e->p.lds_stage_off;
+    io.lds_scratch_off = e->p.lds_scratch_off;
     io.env_mask = env_mask;
     io.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -484,6 +494,16 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.scal = e->d_scal;
     io.dist_ring = e->d_ring;
     io.grid_rows = e->d_rows;
+    io.B = e->p.B;
+    io.H = e->p.H;
+    io.W = e->p.W;
+    io.eps_floor = e->p.eps_floor;
+    io.steps_per_episode = e->p.steps_per_episode;
+    io.den_r = e->p.den_r;
+    io.den_c = e->p.den_c;
+    io.lds_tab_off = e->p.lds_tab_off;
+    io.lds_stage_off = e->p.lds_stage_off;
+    io.lds_scratch_off = e->p.lds_scratch_off;
     io.actions = actions;
     io.obs = obs;
     io.rewards = rewards;
@@ -507,6 +527,16 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.scal = e->d_scal;
     io.dist_ring = e->d_ring;
     io.grid_rows = e->d_rows;
+    io.B = e->p.B;
+    io.H = e->p.H;
+    io.W = e->p.W;
+    io.eps_floor = e->p.eps_floor;
+    io.steps_per_episode = e->p.steps_per_episode;
+    io.den_r = e->p.den_r;
+    io.den_c = e->p.den_c;
+    io.lds_tab_off = e->p.lds_tab_off;
+    io.lds_stage_off = e->p.lds_stage_off;
+    io.lds_scratch_off = e->p.lds_scratch_off;
     io.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
