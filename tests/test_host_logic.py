@@ -1,0 +1,163 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header declares,
+config validation, obs layout, named-grid tables, workload + sharding helpers, harness CLI."""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from trace_util import ROOT, load_golden
+
+
+def _lib():
+    from dl_reference_models_amd import _lib as L
+
+    return L, L.load()
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    L, lib = _lib()
+    header = open(os.path.join(ROOT, "include", "mapf_step.h")).read()
+    declared = sorted(set(re.findall(r"\b(mapf_[a-z_]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"libmapfstep.so does not export {name}"
+    assert sorted(L.EXPORTED_SYMBOLS) == declared
+    assert lib.mapf_version() == (0 << 16) | 1
+
+
+def test_obs_len_matches_reference_layout():
+    L, lib = _lib()
+    for sr in (0, 1, 2, 3, 5):
+        for dist in (0, 1):
+            for pressure in (0, 1):
+                for mask in (0, 1):
+                    flags = (L.FLAG_GOAL_DISTANCE * dist) | (L.FLAG_BLOCKING_PRESSURE * pressure) | (L.FLAG_ACTION_MASK * mask)
+                    cfg = L.MapfConfig(1, 8, 8, 2, sr, 100, flags, 8, 16, 2, 1, 1.0, 0, 0)
+                    want = (2 * sr + 1) ** 2 + 2 + dist + pressure + 5 * mask
+                    assert lib.mapf_obs_len(C.byref(cfg)) == want
+    # reference default (MA-env:43-45): sensor_range 1 -> 3*3 + 2 + 1 = 12; benchmark default sr 2 -> 28
+    from dl_reference_models_amd.workloads import obs_len
+
+    assert obs_len({"sensor_range": 2}) == 28 and obs_len({"sensor_range": 2, "include_action_mask_in_obs": True}) == 33
+
+
+@pytest.mark.parametrize("bad", [
+    dict(num_envs=0), dict(height=65), dict(width=0), dict(num_agents=65), dict(num_agents=0), dict(sensor_range=6),
+    dict(deadlock_window_steps=65), dict(livelock_window_steps=100), dict(lanes_per_env=3), dict(lanes_per_env=4, num_agents=8),
+])
+def test_create_rejects_configs_outside_the_build_limits_without_touching_the_gpu(bad):
+    L, lib = _lib()
+    kw = dict(num_envs=4, height=8, width=8, num_agents=2, sensor_range=1, steps_per_episode=100, flags=0,
+              deadlock_window_steps=8, livelock_window_steps=16, lock_nearby_manhattan=2, lock_min_neighbors=1,
+              lock_progress_epsilon=1.0, device=0, lanes_per_env=0)
+    kw.update(bad)
+    cfg = L.MapfConfig(*[kw[f[0]] for f in L.MapfConfig._fields_])
+    h = C.c_void_p()
+    assert lib.mapf_create(C.byref(cfg), C.byref(h)) == L.MAPF_ERR_CONFIG
+    assert h.value is None and lib.mapf_last_error(None)
+
+
+def test_named_grid_tables_match_the_reference_data():
+    from dl_reference_models_amd import get_grid as gg
+
+    assert len(gg.grid_names()) == 8
+    shapes = {"1-1": (2, 9), "1-2": (3, 10), "1-3": (5, 3), "1-4": (7, 7), "2-1": (10, 20), "2-1-b": (10, 20),
+              "2-2": (15, 21), "3-1": (20, 30)}
+    for k, shp in shapes.items():
+        g = gg.get_grid("ReferenceModel-" + k)
+        assert g.shape == shp and g.dtype == np.uint8 and set(np.unique(g)) <= {0, 1}
+    # grids recorded in the golden traces come straight from the reference's get_grid
+    assert np.array_equal(gg.get_grid("ReferenceModel-2-1"), load_golden("g5_named_2_1")["grids"][0])
+    assert np.array_equal(gg.get_grid("ReferenceModel-3-1"), load_golden("g5_named_3_1")["grids"][0])
+    assert gg.get_start_positions("ReferenceModel-2-1", 2) == {"agent_0": (5, 0), "agent_1": (3, 12)}
+    assert gg.get_goal_positions("ReferenceModel-2-1", 2) == {"agent_0": (6, 6), "agent_1": (9, 3)}
+    fx = load_golden("g5_named_2_2")
+    s = gg.get_start_positions("ReferenceModel-2-2", 4)
+    assert [list(s[f"agent_{i}"]) for i in range(4)] == fx["ctor_starts"][0].tolist()
+    with pytest.raises(ValueError, match="Unknown environment name"):
+        gg.get_grid("nope")
+    with pytest.raises(ValueError, match="Unknown environment name"):
+        gg.get_start_positions("ReferenceModel-2-1-b", 2)  # no fixed table (get_grid.py:790-792)
+    with pytest.raises(ValueError, match="exceeds available positions"):
+        gg.get_start_positions("ReferenceModel-1-1", 3)
+    with pytest.raises(ValueError, match="exceeds available goal positions"):
+        gg.get_goal_positions("ReferenceModel-2-1", 5)
+
+
+def test_workload_definitions_are_functions_of_the_global_env_index():
+    from dl_reference_models_amd import workloads as wl
+
+    a = wl.workload_config("c3_8192x32x32_n8", [5, 6, 7])
+    b = wl.workload_config("c3_8192x32x32_n8", [7])
+    assert np.array_equal(a["grid"][2], b["grid"][0]) and a["seeds"][2] == b["seeds"][0] == 7
+    assert (a["grid"] == 0).sum(axis=(1, 2)).min() >= 16
+    g = wl.synthetic_grid(3, 32, 32, 0.40, 8)
+    assert np.array_equal(g, (np.random.default_rng(10_003).random((32, 32)) < 0.40).astype(np.uint8))
+    # c2 1070 B, c3 2530 B, c5 15290 B per env-step
+    assert wl.algorithmic_bytes_per_env_step(4, 33, 16, 16) == 1070
+    assert wl.algorithmic_bytes_per_env_step(8, 33, 32, 32) == 2530
+    assert wl.algorithmic_bytes_per_env_step(64, 33, 64, 64) == 15290
+
+
+def test_shard_ranges_partition_the_env_index_space():
+    from dl_reference_models_amd.sharding import shard_range, weak_range
+
+    for total, world in ((65536, 8), (1003, 4), (7, 8), (8192, 1)):
+        seen = []
+        for r in range(world):
+            seen += list(shard_range(total, world, r))
+        assert seen == list(range(total))
+    assert list(weak_range(4, 3)) == [12, 13, 14, 15]
+
+
+def test_fallback_spaces_behave_like_gymnasium_spaces():
+    from dl_reference_models_amd.spaces import Box, Discrete, MultiBinary
+
+    b = Box(low=0, high=4, shape=(5, 5), dtype=np.uint8)
+    assert b.shape == (5, 5) and b.contains(np.zeros((5, 5), np.uint8)) and not b.contains(np.full((5, 5), 9, np.uint8))
+    assert not b.contains(np.zeros((4, 5), np.uint8))
+    f = Box(low=np.zeros(3, np.float32), high=np.ones(3, np.float32), dtype=np.float32)
+    assert f.contains(np.array([0, 0.5, 1], np.float32)) and not f.contains(np.array([0, 0.5, 1.5], np.float32))
+    d = Discrete(5)
+    assert d.n == 5 and d.contains(4) and not d.contains(5) and 0 <= d.sample() < 5
+    m = MultiBinary(5)
+    assert m.shape == (5,) and m.dtype == np.int8
+
+
+def test_benchmark_cli_mirrors_the_reference_defaults():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_cli", os.path.join(ROOT, "scripts", "benchmark_multi_agent_env.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.parse_args([])
+    # reference scripts/benchmark_multi_agent_env.py:138-158
+    assert (a.env_name, a.num_agents, a.sensor_range, a.steps_per_episode, a.steps, a.warmup_steps) == \
+        ("ReferenceModel-2-1", 4, 2, 100, 40000, 5000)
+    assert (a.modes, a.env_seed, a.action_seed, a.deterministic, a.info_mode) == ("random,masked", 123, 999, False, "lite")
+    assert str(a.output_dir) == "experiments/results/benchmarks" and a.assert_min_steps_per_s is None
+    a.modes = ["random"]
+    cfg = mod._build_env_config(a)
+    assert cfg == {"env_name": "ReferenceModel-2-1", "seed": 123, "deterministic": False, "num_agents": 4,
+                   "steps_per_episode": 100, "sensor_range": 2, "info_mode": "lite",
+                   "training_execution_mode": "CTDE", "render_env": False}
+    r = mod._result("random", 10, 2, 3, 0.5, cfg, 4, 4, {})
+    assert r["steps_per_s"] == 80.0 and r["agent_steps_per_s"] == 320.0 and r["mean_step_ms"] == 50.0
+    assert list(r)[:9] == ["mode", "steps", "warmup_steps", "episodes_completed", "elapsed_s", "steps_per_s",
+                           "episodes_per_s", "mean_step_ms", "env_config"]
+
+
+def test_product_package_never_imports_the_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "dl_reference_models_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".inl", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "mapf_oracle" not in text and "from oracle" not in text, f
+    assert "oracle" not in open(os.path.join(ROOT, "scripts", "benchmark_multi_agent_env.py")).read()
