@@ -86,7 +86,8 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun always go through RCCL, also at world size 1
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
     name = args.workload or wl.HEADLINE
@@ -142,7 +143,7 @@ def main():
             run_plain(0, k)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -159,7 +160,7 @@ def main():
     # back-to-back boundary; graph replays leave no host gap).  This is the roofline's kernel time.
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     env.poll_error()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -179,7 +180,7 @@ def main():
     # off the timed path: optional RCCL sum of episode statistics (64-byte message, latency-bound)
     st = env.get_state()["counters"]
     stats = np.array([float(st[:, 9].sum())], dtype=np.float64)
-    stats = sharding.all_reduce_stats(stats, device=device if world > 1 else None)
+    stats = sharding.all_reduce_stats(stats, device=device if use_dist else None)
 
     agent_steps = b_per * n * args.steps * world
     bytes_per_launch = wl.algorithmic_bytes_per_env_step(n, L, h, w) * b_per
@@ -225,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(name, env_ids, args.cpu_steps, action_pool_np)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

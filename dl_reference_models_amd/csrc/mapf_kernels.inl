@@ -153,6 +153,20 @@ __device__ __forceinline__ uint64_t gballot(bool pred, int lane) {
     return (b >> (lane & ~(LPE - 1))) & group_mask<LPE>();
 }
 
+// group ballot in the narrowest register type that holds one bit per lane of the group
+template <int LPE>
+struct GMask {
+    using type = uint32_t;
+};
+template <>
+struct GMask<64> {
+    using type = uint64_t;
+};
+template <int LPE>
+__device__ __forceinline__ typename GMask<LPE>::type gballot_n(bool pred, int lane) {
+    return (typename GMask<LPE>::type)gballot<LPE>(pred, lane);
+}
+
 // OR the per-group bit sets of a wave ballot together (bit i = "some group has agent i set")
 template <int LPE>
 __device__ __forceinline__ uint64_t fold_groups(uint64_t m) {
@@ -328,6 +342,20 @@ __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, La
     }
 }
 
+// 16-byte state store; MAPF_STATE_STORE: 0 = plain (line stays in L2), 2 = sc1 write-through
+#ifndef MAPF_STATE_STORE
+#define MAPF_STATE_STORE 0
+#endif
+__device__ __forceinline__ void store_state16(void *dst, const uint4 v) {
+#if MAPF_STATE_STORE == 2
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+#else
+    *reinterpret_cast<uint4 *>(dst) = v;
+#endif
+}
+
 __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
     uint4 *rp = reinterpret_cast<uint4 *>(rec);
     uint4 q0, q1;
@@ -339,8 +367,8 @@ __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
     q1.y = (uint32_t)(st.failed >> 32);
     q1.z = (uint32_t)st.progress;
     q1.w = (uint32_t)(st.progress >> 32);
-    rp[0] = q0;
-    rp[1] = q1;
+    store_state16(rp, q0);
+    store_state16(rp + 1, q1);
 }
 
 __device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
@@ -352,9 +380,9 @@ __device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
 }
 __device__ __forceinline__ void store_scal(int *scal, int env, const int *sc) {
     int4 *sp = reinterpret_cast<int4 *>(scal + (size_t)env * kScalInts);
-    sp[0] = make_int4(sc[0], sc[1], sc[2], sc[3]);
-    sp[1] = make_int4(sc[4], sc[5], sc[6], sc[7]);
-    sp[2] = make_int4(sc[8], sc[9], sc[10], sc[11]);
+    store_state16(sp, make_uint4(sc[0], sc[1], sc[2], sc[3]));
+    store_state16(sp + 1, make_uint4(sc[4], sc[5], sc[6], sc[7]));
+    store_state16(sp + 2, make_uint4(sc[8], sc[9], sc[10], sc[11]));
 }
 
 __device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
@@ -396,40 +424,41 @@ __device__ __forceinline__ void raise_error(const Params &p, int code, int env, 
 template <class K, int LPE>
 __device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, int lane, int a, uint32_t old,
                                                   uint32_t tgt) {
+    using gm_t = typename GMask<LPE>::type;
     constexpr int C = LPE < 8 ? LPE : 8;
     const int N = K::N(p);
     tabg[a] = make_uint2(old, tgt);  // idle lanes publish {kIdleCell, kNoCell}: they match nothing
     wave_lds_sync();
-    int occ_by = -1;
-    uint32_t cont_lo = 0, cont_hi = 0;  // lower-index contenders for my target
+    gm_t occ_bit = 0;  // the agent standing on my target (positions are unique: at most one)
+    gm_t cont = 0;     // lower-index contenders for my target
     const bool want = tgt != kNoCell;
+    const gm_t below = ((gm_t)1 << a) - 1;  // indices < a
     for (int j0 = 0; j0 < N; j0 += C) {
         uint2 e[C];
 #pragma unroll
         for (int u = 0; u < C; u++) e[u] = tabg[j0 + u];
 #pragma unroll
         for (int u = 0; u < C; u++) {
-            const int j = j0 + u;
-            if (e[u].x == tgt) occ_by = j;  // positions are unique: at most one occupant
-            const bool c = want && j < a && e[u].y == tgt;
-            if (LPE <= 32 || j < 32) cont_lo |= c ? (1u << (j & 31)) : 0u;
-            else cont_hi |= c ? (1u << (j & 31)) : 0u;
+            const gm_t bit = (gm_t)1 << (j0 + u);
+            occ_bit |= (e[u].x == tgt) ? bit : 0;
+            cont |= (e[u].y == tgt) ? bit : 0;
         }
     }
-    const uint64_t cont = (uint64_t)cont_lo | ((uint64_t)cont_hi << 32);
-    const bool occ_low = occ_by >= 0 && occ_by < a;
-    const uint64_t dep = cont | (occ_low ? (1ull << occ_by) : 0ull);
+    cont = want ? (cont & below) : 0;
+    const gm_t occ_low = occ_bit & below;    // occupant has a lower index: blocked unless it moved away
+    const bool occ_high = (occ_bit & ~below) != 0;  // occupant has a higher index (never me: tgt != old): blocked
+    const gm_t dep = cont | occ_low;
     bool resolved = !want, moved = false;
-    uint64_t R = gballot<LPE>(resolved, lane), M = 0;
+    gm_t R = gballot_n<LPE>(resolved, lane), M = 0;
+#pragma unroll 1
     for (int it = 0; it <= N; it++) {
         if (__all(resolved)) break;
         if (!resolved && (dep & ~R) == 0) {
-            const bool blocked = (occ_by > a) || (occ_low && !((M >> occ_by) & 1ull)) || (cont & M) != 0;
-            moved = !blocked;
+            moved = !(occ_high || (occ_low & ~M) != 0 || (cont & M) != 0);
             resolved = true;
         }
-        R = gballot<LPE>(resolved, lane);
-        M = gballot<LPE>(moved, lane);
+        R = gballot_n<LPE>(resolved, lane);
+        M = gballot_n<LPE>(moved, lane);
     }
     wave_lds_sync();  // the table region is rewritten after this point
     return moved ? tgt : old;
@@ -575,6 +604,54 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
 // copy the wave's staged observations to global memory.  sel (per lane, uniform inside a group):
 // 0 -> io.obs, 1 -> io.final_obs, 2 -> skip.  Flat 16-byte stores when every valid group goes to
 // the same tensor, otherwise one contiguous run per group.
+// Observation stream stores.  The 8.6 MB of observations a launch writes are not re-read by this engine, so
+// they are pushed towards HBM while the kernel runs (write-through) instead of sitting dirty in L2 until the
+// end-of-kernel write-back: 0 = plain, 1 = nontemporal, 2 = sc1 write-through.
+#ifndef MAPF_OBS_STORE
+#define MAPF_OBS_STORE 2
+#endif
+__device__ __forceinline__ void store_obs4(float4 *dst, const float4 v) {
+#if MAPF_OBS_STORE == 1
+    __builtin_nontemporal_store(v.x, &dst->x);
+    __builtin_nontemporal_store(v.y, &dst->y);
+    __builtin_nontemporal_store(v.z, &dst->z);
+    __builtin_nontemporal_store(v.w, &dst->w);
+#elif MAPF_OBS_STORE == 2
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+#else
+    *dst = v;
+#endif
+}
+
+// full wave, one destination, compile-time shape: straight-line 16-byte copies
+template <class K, int LPE>
+__device__ __forceinline__ void flush_obs_full(const Params &p, float *flat, const float *stage, int lane, int env0) {
+    constexpr int G = 64 / LPE;
+    const int NL = K::N(p) * K::L(p);
+    const int n = G * NL;
+    float *dst = flat + (size_t)env0 * NL;
+    if (K::kFixed && (n & 3) == 0) {
+        const int n4 = n >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(stage);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const int full = n4 >> 6;  // rounds in which all 64 lanes copy
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (r < full) store_obs4(d4 + r * 64 + lane, s4[r * 64 + lane]);
+        }
+        if ((full << 6) + lane < n4) store_obs4(d4 + (full << 6) + lane, s4[(full << 6) + lane]);
+    } else if ((n & 3) == 0) {
+        const int n4 = n >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(stage);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int k = lane; k < n4; k += 64) d4[k] = s4[k];
+    } else {
+        for (int k = lane; k < n; k += 64) dst[k] = stage[k];
+    }
+}
+
 template <class K, int LPE>
 __device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const float *stage, int lane, int env0,
                                           int ngroups, int sel) {
@@ -785,57 +862,41 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // ------------------------------------------------------------------------------------------------
 // step kernel (MA-env:474-695)
 // ------------------------------------------------------------------------------------------------
-template <class K, int LPE, int MW>
-__global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
-    const Params &p = *pp;
+// FAST = the wave is full (every group is a live env, every lane an agent) and no lane carries an invalid
+// action: every validity predicate below is then a compile-time constant and the error bookkeeping vanishes.
+// The general body handles ragged batches, N < LPE and the reference's mid-loop ValueError.
+template <class K, int LPE, int MW, bool FAST>
+__device__ __forceinline__ void step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
+                                          const int ngroups, int act, Lane &st, int *sc, const uint4 rq0,
+                                          const uint4 rq1) {
     constexpr int G = 64 / LPE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds l = carve_lds(io, lds_raw);
-    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
-    const int env0 = blockIdx.x * G;
-    const int ngroups = min(G, io.B - env0);
-    const bool env_ok = grp < ngroups;
+    const int grp = lane / LPE, a = lane % LPE;
+    const bool env_ok = FAST ? true : (grp < ngroups);
     const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p), H = io.H, W = io.W;
     const uint32_t flags = K::flags(p);
-    const bool is_agent = env_ok && a < N;
+    const bool is_agent = FAST ? true : (env_ok && a < N);
     const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0;
     const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
     uint4 *tabg = l.tab + grp * LPE;
     const uint64_t *myrows = l.rows + grp * H;
     AgentRec *rec = io.agents + (size_t)env * N + a;
-
-    MAPF_STAMP(0);
-    // ---- loads: obstacle rows -> LDS, agent record, env scalars, action, distance ring; all in flight together
-    load_rows_to_lds(io.grid_rows, H, l.rows, lane, env0, ngroups);
-    Lane st;
-    load_lane(rec, is_agent, st);
-    int sc[12];
-    load_scal(io.scal, env, sc);
-    int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
-    const bool ring_pre = lock_on && ring_stride <= 16;  // whole per-agent ring fits two 16-byte loads
+    const bool ring_pre = lock_on && ring_stride <= 16;
     int16_t *ring = io.dist_ring + ((size_t)env * N + a) * ring_stride;
-    uint4 rq0 = make_uint4(0, 0, 0, 0), rq1 = make_uint4(0, 0, 0, 0);
-    if (ring_pre && is_agent) {
-        rq0 = reinterpret_cast<const uint4 *>(ring)[0];
-        if (ring_stride > 8) rq1 = reinterpret_cast<const uint4 *>(ring)[1];
-    }
-    wave_lds_sync();
-#ifdef MAPF_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
-#endif
-    MAPF_STAMP(1);
 
     // ---- invalid action: the reference raises mid-loop, after the agents before the bad one were
     //      processed (MA-env:502-506); reproduce the partial mutation and latch the error ---------
-    const bool bad = is_agent && (act < 0 || act > 4);
-    const uint64_t badm = gballot<LPE>(bad, lane);
-    const bool errored = badm != 0;
-    const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
-    const bool live = is_agent && a < n_live;
-    if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
-    if (!live) act = 0;
+    bool errored = false, live = is_agent;
+    if (!FAST) {
+        const bool bad = is_agent && (act < 0 || act > 4);
+        const uint64_t badm = gballot<LPE>(bad, lane);
+        errored = badm != 0;
+        const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+        live = is_agent && a < n_live;
+        if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
+        if (!live) act = 0;
+    }
 
     sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
 
@@ -931,9 +992,14 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     // ---- everything below is skipped by the reference when the ValueError fired; such groups keep
     //      only the mutations made before the exception ----------------------------------------------
     int sc_keep[12];
+    uint64_t h_moved = 0, h_failed = 0, h_progress = 0;
+    if (!FAST) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) sc_keep[k] = sc[k];
-    const uint64_t h_moved = st.moved, h_failed = st.failed, h_progress = st.progress;
+        for (int k = 0; k < 12; k++) sc_keep[k] = sc[k];
+        h_moved = st.moved;
+        h_failed = st.failed;
+        h_progress = st.progress;
+    }
 
     // lock flags (MA-env:581-594) and distance ring
     const bool cur_on_goal = is_agent && cur == st.goal;
@@ -975,6 +1041,25 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
         sc[MAPF_CTR_HIST_ROWS] = t + 1;
     }
 
+    // termination (MA-env:668-690) only needs on_goal and the step counter, so it is decided BEFORE the pair
+    // pass: the observation stores can then leave right after the emit and drain under the rest of the step.
+    // Success check precedes the step-limit check.
+    int term = 0, trunc = 0;
+    float term_reward = 0.0f;
+    {
+        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+        if (!lifelong && n_on_goal == N) {
+            term_reward = 1.0f;
+            term = 1;
+        } else if (sc[MAPF_CTR_STEP_COUNT] >= io.steps_per_episode) {
+            if (!lifelong && !on_goal) term_reward = -1.0f;
+            term = 1;
+            trunc = 1;
+        }
+    }
+    const bool done = env_ok && !errored && (term | trunc);
+    const bool do_reset = done && io.auto_reset;
+
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
     {
@@ -991,26 +1076,39 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     observe<K, LPE, MW, true>(p, io, myrows, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a, cur, st.goal,
                               reassigned, pressure_prev, delta, po);
     MAPF_STAMP(4);
+
+    // ---- observations leave the wave as one contiguous stream ------------------------------------
+    wave_lds_sync();
+    if (FAST && !__any(do_reset)) {
+        if (io.obs) flush_obs_full<K, LPE>(p, io.obs, l.stage, lane, env0);
+    } else if (io.obs || io.final_obs) {
+        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
+    }
+    MAPF_STAMP(5);
+
+    reward += term_reward;
     reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
 
     // lock detector (MA-env:400-438): deadlock has priority over livelock
+    using gm_t = typename GMask<LPE>::type;
     int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
     if (lock_on) {
         const uint64_t mdw = dw >= 64 ? ~0ull : ((1ull << dw) - 1ull);
         const uint64_t mlw = lw >= 64 ? ~0ull : ((1ull << lw) - 1ull);
-        const uint64_t members = po.nbr | (1ull << a);
-        const bool focal = is_agent && !cur_on_goal && __popcll(po.nbr) >= K::min_nbrs(p);
-        const uint64_t prog_dw_nz = gballot<LPE>(is_agent && (st.progress & mdw) != 0, lane);
-        const uint64_t moved_dw_nz = gballot<LPE>(is_agent && (st.moved & mdw) != 0, lane);
-        const uint64_t fail_dw_nz = gballot<LPE>(is_agent && (st.failed & mdw) != 0, lane);
-        const uint64_t prog_lw_nz = gballot<LPE>(is_agent && (st.progress & mlw) != 0, lane);
-        const uint64_t moved_lw_nz = gballot<LPE>(is_agent && (st.moved & mlw) != 0, lane);
-        const bool dead_me = focal && dl_ok && (members & prog_dw_nz) == 0 && (members & moved_dw_nz) == 0 &&
-                             (members & fail_dw_nz) != 0;
+        const gm_t nbr = (gm_t)po.nbr;
+        const gm_t members = nbr | ((gm_t)1 << a);
+        const bool focal = is_agent && !cur_on_goal && __popcll((uint64_t)nbr) >= K::min_nbrs(p);
+        const gm_t prog_dw_nz = gballot_n<LPE>(is_agent && (st.progress & mdw) != 0, lane);
+        const gm_t moved_dw_nz = gballot_n<LPE>(is_agent && (st.moved & mdw) != 0, lane);
+        const gm_t fail_dw_nz = gballot_n<LPE>(is_agent && (st.failed & mdw) != 0, lane);
+        const gm_t prog_lw_nz = gballot_n<LPE>(is_agent && (st.progress & mlw) != 0, lane);
+        const gm_t moved_lw_nz = gballot_n<LPE>(is_agent && (st.moved & mlw) != 0, lane);
+        const bool dead_me = focal && dl_ok && (members & (prog_dw_nz | moved_dw_nz)) == 0 && (members & fail_dw_nz) != 0;
         const bool live_me = focal && ll_ok && (members & prog_lw_nz) == 0 && (members & moved_lw_nz) != 0 &&
                              po.sum_delta <= io.eps_floor;
-        deadlock = gballot<LPE>(dead_me, lane) != 0;
-        livelock = !deadlock && gballot<LPE>(live_me, lane) != 0;
+        deadlock = gballot_n<LPE>(dead_me, lane) != 0;
+        livelock = !deadlock && gballot_n<LPE>(live_me, lane) != 0;
         const int prev = sc[MAPF_CTR_LOCK_STATE_PREV];
         dl_event = deadlock && !(prev & 1);  // rising edges MA-env:599-600
         ll_event = livelock && !(prev & 2);
@@ -1026,56 +1124,24 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const int blocking_step = __popcll(gballot<LPE>(blocking, lane));
     sc[MAPF_CTR_BLOCKING_COUNT] += blocking_step;
 
-    // termination (MA-env:668-690): success check precedes the step-limit check
-    int term = 0, trunc = 0;
-    const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
-    if (!lifelong && n_on_goal == N) {
-        reward += 1.0f;
-        term = 1;
-    } else if (sc[MAPF_CTR_STEP_COUNT] >= io.steps_per_episode) {
-        if (!lifelong && !on_goal) reward -= 1.0f;
-        term = 1;
-        trunc = 1;
-    }
-    const bool done = env_ok && !errored && (term | trunc);
-    const bool do_reset = done && io.auto_reset;
-
-    // ---- observations leave the wave as one contiguous stream ------------------------------------
-    wave_lds_sync();
-    MAPF_STAMP(5);
-    if (io.obs || io.final_obs) {
-        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
-    }
-
     MAPF_STAMP(6);
     // ---- per-step outputs: info (MA-env:627-656), rewards, done flags --------------------------------
     {
         const int reached_cnt = __popcll(gballot<LPE>(is_agent && reached, lane));
         const int completed_cnt = __popcll(gballot<LPE>(is_agent && completed, lane));
         const int goals_total = lifelong ? sc[MAPF_CTR_GOALS_REACHED_TOTAL] : reached_cnt;
-        if (io.info_all && env_ok && !errored) {
+        if (io.info_all && env_ok && !errored && a == 0) {
             const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
-            for (int k = a; k < MAPF_INFO_ALL; k += LPE) {
-                float v;
-                switch (k) {
-                    case 0: v = (float)goals_step; break;
-                    case 1: v = (float)goals_total; break;
-                    case 2: v = (float)blocking_step; break;
-                    case 3: v = (float)sc[MAPF_CTR_BLOCKING_COUNT]; break;
-                    case 4: v = (float)deadlock; break;
-                    case 5: v = (float)livelock; break;
-                    case 6: v = (float)dl_event; break;
-                    case 7: v = (float)ll_event; break;
-                    case 8: v = (float)sc[MAPF_CTR_DEADLOCK_EVENTS]; break;
-                    case 9: v = (float)sc[MAPF_CTR_LIVELOCK_EVENTS]; break;
-                    case 10: v = (float)sc[MAPF_CTR_DEADLOCK_STEPS]; break;
-                    case 11: v = (float)sc[MAPF_CTR_LIVELOCK_STEPS]; break;
-                    case 12: v = (float)completed_cnt / (float)N; break;  // completion_ratio MA-env:638
-                    default: v = (float)goals_total / (float)steps; break;  // throughput MA-env:655
-                }
-                io.info_all[(size_t)env * MAPF_INFO_ALL + k] = v;
-            }
+            float *ia = io.info_all + (size_t)env * MAPF_INFO_ALL;  // 56 bytes per env: 8-byte aligned
+            float2 *ia2 = reinterpret_cast<float2 *>(ia);
+            ia2[0] = make_float2((float)goals_step, (float)goals_total);
+            ia2[1] = make_float2((float)blocking_step, (float)sc[MAPF_CTR_BLOCKING_COUNT]);
+            ia2[2] = make_float2((float)deadlock, (float)livelock);
+            ia2[3] = make_float2((float)dl_event, (float)ll_event);
+            ia2[4] = make_float2((float)sc[MAPF_CTR_DEADLOCK_EVENTS], (float)sc[MAPF_CTR_LIVELOCK_EVENTS]);
+            ia2[5] = make_float2((float)sc[MAPF_CTR_DEADLOCK_STEPS], (float)sc[MAPF_CTR_LIVELOCK_STEPS]);
+            ia2[6] = make_float2((float)completed_cnt / (float)N,        // completion_ratio MA-env:638
+                                 (float)goals_total / (float)steps);      // throughput MA-env:655
         }
         if (is_agent && !errored) {
             if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
@@ -1095,7 +1161,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     MAPF_STAMP(7);
     // ---- state image after the step -----------------------------------------------------------
     st.pos = cur;
-    if (errored) {
+    if (!FAST && errored) {
 #pragma unroll
         for (int k = 0; k < 12; k++) sc[k] = sc_keep[k];
         st.moved = h_moved;
@@ -1122,6 +1188,48 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
 #endif
     MAPF_STAMP(9);
+}
+
+template <class K, int LPE, int MW>
+__global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Lds l = carve_lds(io, lds_raw);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, io.B - env0);
+    const int N = K::N(p);
+    const bool full = ngroups == G && N == LPE;  // wave-uniform
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    const bool is_agent = env_ok && a < N;
+    const bool lock_on = (K::flags(p) & MAPF_FLAG_LOCK_METRICS) != 0;
+    const int ring_stride = K::ring_stride(p);
+
+    MAPF_STAMP(0);
+    // ---- loads: agent record, env scalars, action, distance ring, obstacle rows -> LDS; all in flight together
+    Lane st;
+    load_lane(io.agents + (size_t)env * N + a, full || is_agent, st);
+    int act = (full || is_agent) ? (int)io.actions[(size_t)env * N + a] : 0;
+    int sc[12];
+    load_scal(io.scal, env, sc);
+    uint4 rq0 = make_uint4(0, 0, 0, 0), rq1 = make_uint4(0, 0, 0, 0);
+    if (lock_on && ring_stride <= 16 && (full || is_agent)) {  // whole per-agent ring fits two 16-byte loads
+        const uint4 *rp = reinterpret_cast<const uint4 *>(io.dist_ring + ((size_t)env * N + a) * ring_stride);
+        rq0 = rp[0];
+        if (ring_stride > 8) rq1 = rp[1];
+    }
+    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    wave_lds_sync();
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
+#endif
+    MAPF_STAMP(1);
+    if (full && !__any(act < 0 || act > 4))
+        step_body<K, LPE, MW, true>(p, io, l, lane, env0, ngroups, act, st, sc, rq0, rq1);
+    else
+        step_body<K, LPE, MW, false>(p, io, l, lane, env0, ngroups, act, st, sc, rq0, rq1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ for t in range(20):
     rows.append(buf.reshape(blocks, 16)[:, :10].astype(np.int64))
 st = np.stack(rows)  # [T, blocks, 10]
 d = np.diff(st, axis=2)
-names = ["loads+sync", "move", "goal/lock/table", "pair loop+emit", "lock/term ballots", "flush obs", "outputs",
+names = ["loads+sync", "move", "goal/lock/term/table", "pair loop+emit", "flush obs", "lock detector", "outputs",
          "state stores", "drain stores"]
 tot = st[:, :, 9] - st[:, :, 0]
 print(f"workload {name}: {blocks} waves; s_memtime ticks are shader cycles (100 MHz-based clock on gfx950: see guide)")
