@@ -26,14 +26,17 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // device-side data layout
 // ------------------------------------------------------------------------------------------------
-// Agent record, 32 B, array [B][N] (env-major; a wave reads 64 consecutive records = 2 KiB).
+// Agent record, 48 B, array [B][N] (env-major; a wave reads 64 consecutive records = 3 KiB).
 //   w0: pos (row<<8 | col) | goal<<16      w1: start | flags<<16
 //   moved / failed / progress: lock-history shift registers, bit k = flag k steps ago
+//   dist[4]: goal-distance history as 16 x uint8, byte k = distance k steps ago (used when the livelock
+//            window is <= 16 steps; longer windows use the separate int16 ring)
 struct AgentRec {
     uint32_t w0, w1;
     uint64_t moved, failed, progress;
+    uint32_t dist[4];
 };
-static_assert(sizeof(AgentRec) == 32, "AgentRec must be 32 bytes");
+static_assert(sizeof(AgentRec) == 48, "AgentRec must be 48 bytes");
 
 constexpr int kFlagReached = 1, kFlagCompleted = 2, kFlagPressure = 4;
 constexpr int kScalInts = MAPF_NUM_COUNTERS;  // 16 int32 = 64 B per env
@@ -68,7 +71,7 @@ struct Params {
 struct Io {
     AgentRec *agents;
     int *scal;
-    int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw
+    int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw (only when lw > 16)
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
     // hot scalars (copies of the Params fields every launch needs before its first memory access)
     int B, H, W, eps_floor, steps_per_episode;
@@ -320,12 +323,14 @@ struct Lane {
     uint32_t pos, goal, start;  // row<<8|col
     uint32_t flags;
     uint64_t moved, failed, progress;
+    uint4 dist;  // 16 x uint8 goal-distance history
 };
 
 __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
     if (is_agent) {
         const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
         uint4 q0 = rp[0], q1 = rp[1];
+        st.dist = rp[2];
         st.pos = q0.x & 0xFFFFu;
         st.goal = q0.x >> 16;
         st.start = q0.y & 0xFFFFu;
@@ -339,6 +344,7 @@ __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, La
         st.start = kIdleCell;
         st.flags = 0;
         st.moved = st.failed = st.progress = 0;
+        st.dist = make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -369,6 +375,7 @@ __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
     q1.w = (uint32_t)(st.progress >> 32);
     store_state16(rp, q0);
     store_state16(rp + 1, q1);
+    store_state16(rp + 2, st.dist);
 }
 
 __device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
@@ -606,47 +613,63 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
 // the same tensor, otherwise one contiguous run per group.
 // Observation stream stores.  The 8.6 MB of observations a launch writes are not re-read by this engine, so
 // they are pushed towards HBM while the kernel runs (write-through) instead of sitting dirty in L2 until the
-// end-of-kernel write-back: 0 = plain, 1 = nontemporal, 2 = sc1 write-through.
+// end-of-kernel write-back (measured: DESIGN.md section 5).  MAPF_OBS_STORE: 0 = plain, 1 = nontemporal,
+// 2 = sc1 write-through.  The sc1 form is a buffer store with the cache-policy bit (aux 16), a store hipcc
+// can see: an inline-asm store reads its data registers asynchronously and the hazard recognizer does not
+// protect them (that variant corrupted 16 floats per wave in the L = 28 specialisation).
 #ifndef MAPF_OBS_STORE
 #define MAPF_OBS_STORE 2
 #endif
-__device__ __forceinline__ void store_obs4(float4 *dst, const float4 v) {
-#if MAPF_OBS_STORE == 1
-    __builtin_nontemporal_store(v.x, &dst->x);
-    __builtin_nontemporal_store(v.y, &dst->y);
-    __builtin_nontemporal_store(v.z, &dst->z);
-    __builtin_nontemporal_store(v.w, &dst->w);
-#elif MAPF_OBS_STORE == 2
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+struct ObsSink {
+    __amdgpu_buffer_rsrc_t rsrc;
+    float *base;
+};
+__device__ __forceinline__ ObsSink make_obs_sink(float *base, unsigned bytes) {
+    ObsSink s;
+    s.base = base;
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);  // wave-uniform operands only
+    return s;
+}
+// store 16 bytes at byte offset `off` of the sink
+__device__ __forceinline__ void store_obs4(const ObsSink &s, unsigned off, const float4 v) {
+#if MAPF_OBS_STORE == 2
+    const v4u_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, s.rsrc, (int)off, 0, 16);  // aux 16 = sc1
+#elif MAPF_OBS_STORE == 1
+    float *d = reinterpret_cast<float *>(reinterpret_cast<char *>(s.base) + off);
+    __builtin_nontemporal_store(v.x, d);
+    __builtin_nontemporal_store(v.y, d + 1);
+    __builtin_nontemporal_store(v.z, d + 2);
+    __builtin_nontemporal_store(v.w, d + 3);
 #else
-    *dst = v;
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(s.base) + off) = v;
 #endif
 }
 
 // full wave, one destination, compile-time shape: straight-line 16-byte copies
 template <class K, int LPE>
-__device__ __forceinline__ void flush_obs_full(const Params &p, float *flat, const float *stage, int lane, int env0) {
+__device__ __forceinline__ void flush_obs_full(const Params &p, const Io &io, float *flat, const float *stage, int lane,
+                                               int env0) {
     constexpr int G = 64 / LPE;
     const int NL = K::N(p) * K::L(p);
     const int n = G * NL;
     float *dst = flat + (size_t)env0 * NL;
-    if (K::kFixed && (n & 3) == 0) {
+    if ((n & 3) == 0) {
+        const ObsSink sink = make_obs_sink(flat, (unsigned)io.B * (unsigned)NL * 4u);
+        const unsigned off0 = (unsigned)env0 * (unsigned)NL * 4u + (unsigned)lane * 16u;
         const int n4 = n >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(stage);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        const int full = n4 >> 6;  // rounds in which all 64 lanes copy
+        if (K::kFixed) {
+            const int full = n4 >> 6;  // rounds in which all 64 lanes copy
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            if (r < full) store_obs4(d4 + r * 64 + lane, s4[r * 64 + lane]);
+            for (int r = 0; r < 16; r++) {
+                if (r < full) store_obs4(sink, off0 + (unsigned)r * 1024u, s4[r * 64 + lane]);
+            }
+            if ((full << 6) + lane < n4) store_obs4(sink, off0 + (unsigned)full * 1024u, s4[(full << 6) + lane]);
+        } else {
+            for (int k = lane; k < n4; k += 64) store_obs4(sink, off0 + (unsigned)(k - lane) * 16u, s4[k]);
         }
-        if ((full << 6) + lane < n4) store_obs4(d4 + (full << 6) + lane, s4[(full << 6) + lane]);
-    } else if ((n & 3) == 0) {
-        const int n4 = n >> 2;
-        const float4 *s4 = reinterpret_cast<const float4 *>(stage);
-        float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int k = lane; k < n4; k += 64) d4[k] = s4[k];
     } else {
         for (int k = lane; k < n; k += 64) dst[k] = stage[k];
     }
@@ -757,6 +780,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         st.pos = st.start;  // MA-env:279 / :453
         st.flags = 0;       // _reached_arr, _completed_once_arr, _blocking_pressure_prev_arr MA-env:447-449
         st.moved = st.failed = st.progress = 0;  // _reset_lock_tracking MA-env:360-372
+        st.dist = make_uint4(0, 0, 0, 0);
         sc[MAPF_CTR_STEP_COUNT] = 0;
         sc[MAPF_CTR_HIST_ROWS] = 0;
         sc[MAPF_CTR_BLOCKING_COUNT] = 0;
@@ -867,8 +891,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // The general body handles ragged batches, N < LPE and the reference's mid-loop ValueError.
 template <class K, int LPE, int MW, bool FAST>
 __device__ __forceinline__ void step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                          const int ngroups, int act, Lane &st, int *sc, const uint4 rq0,
-                                          const uint4 rq1) {
+                                          const int ngroups, int act, Lane &st, int *sc) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const bool env_ok = FAST ? true : (grp < ngroups);
@@ -882,8 +905,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     uint4 *tabg = l.tab + grp * LPE;
     const uint64_t *myrows = l.rows + grp * H;
     AgentRec *rec = io.agents + (size_t)env * N + a;
-    const bool ring_pre = lock_on && ring_stride <= 16;
-    int16_t *ring = io.dist_ring + ((size_t)env * N + a) * ring_stride;
+    const bool dist_in_rec = lw <= 16;  // goal-distance history lives in the agent record
 
     // ---- invalid action: the reference raises mid-loop, after the agents before the bad one were
     //      processed (MA-env:502-506); reproduce the partial mutation and latch the error ---------
@@ -993,6 +1015,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     //      only the mutations made before the exception ----------------------------------------------
     int sc_keep[12];
     uint64_t h_moved = 0, h_failed = 0, h_progress = 0;
+    const uint4 h_dist = st.dist;
     if (!FAST) {
 #pragma unroll
         for (int k = 0; k < 12; k++) sc_keep[k] = sc[k];
@@ -1017,26 +1040,23 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         st.moved = (st.moved << 1) | (moved ? 1ull : 0ull);  // _append_lock_history_step MA-env:374-387
         st.failed = (st.failed << 1) | (failed ? 1ull : 0ull);
         st.progress = (st.progress << 1) | (progress ? 1ull : 0ull);
-        const int slot_new = t % lw;
-        const int slot_old = (slot_new + 1 == lw) ? 0 : slot_new + 1;  // oldest row of the livelock window
         int d_old = dist;
-        if (lw > 1 && ll_ok) {
-            if (ring_pre) {
-                const int dwi = slot_old >> 1;
-                uint32_t w = rq0.x;
-                w = dwi == 1 ? rq0.y : w;
-                w = dwi == 2 ? rq0.z : w;
-                w = dwi == 3 ? rq0.w : w;
-                w = dwi == 4 ? rq1.x : w;
-                w = dwi == 5 ? rq1.y : w;
-                w = dwi == 6 ? rq1.z : w;
-                w = dwi == 7 ? rq1.w : w;
-                d_old = (int)((slot_old & 1) ? (w >> 16) : (w & 0xFFFFu));
-            } else if (is_agent) {
-                d_old = ring[slot_old];
-            }
+        if (dist_in_rec) {
+            // shift the 16-byte history by one step and read the oldest row of the window (byte lw-1)
+            st.dist.w = (st.dist.w << 8) | (st.dist.z >> 24);
+            st.dist.z = (st.dist.z << 8) | (st.dist.y >> 24);
+            st.dist.y = (st.dist.y << 8) | (st.dist.x >> 24);
+            st.dist.x = (st.dist.x << 8) | (uint32_t)dist;
+            const int ob = lw - 1, od = ob >> 2;
+            const uint32_t w = od == 0 ? st.dist.x : (od == 1 ? st.dist.y : (od == 2 ? st.dist.z : st.dist.w));
+            if (ll_ok) d_old = (int)((w >> ((ob & 3) * 8)) & 0xFFu);
+        } else {
+            int16_t *ring = io.dist_ring + ((size_t)env * N + a) * ring_stride;
+            const int slot_new = t % lw;
+            const int slot_old = (slot_new + 1 == lw) ? 0 : slot_new + 1;  // oldest row of the livelock window
+            if (ll_ok && is_agent) d_old = ring[slot_old];
+            if (is_agent && !errored) ring[slot_new] = (int16_t)dist;
         }
-        if (is_agent && !errored) ring[slot_new] = (int16_t)dist;
         delta = d_old - dist;
         sc[MAPF_CTR_HIST_ROWS] = t + 1;
     }
@@ -1080,7 +1100,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     // ---- observations leave the wave as one contiguous stream ------------------------------------
     wave_lds_sync();
     if (FAST && !__any(do_reset)) {
-        if (io.obs) flush_obs_full<K, LPE>(p, io.obs, l.stage, lane, env0);
+        if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
     } else if (io.obs || io.final_obs) {
         const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
         flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
@@ -1167,6 +1187,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         st.moved = h_moved;
         st.failed = h_failed;
         st.progress = h_progress;
+        st.dist = h_dist;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (pressure_prev ? kFlagPressure : 0);
     } else {
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
@@ -1204,8 +1225,6 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
-    const bool lock_on = (K::flags(p) & MAPF_FLAG_LOCK_METRICS) != 0;
-    const int ring_stride = K::ring_stride(p);
 
     MAPF_STAMP(0);
     // ---- loads: agent record, env scalars, action, distance ring, obstacle rows -> LDS; all in flight together
@@ -1214,12 +1233,6 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     int act = (full || is_agent) ? (int)io.actions[(size_t)env * N + a] : 0;
     int sc[12];
     load_scal(io.scal, env, sc);
-    uint4 rq0 = make_uint4(0, 0, 0, 0), rq1 = make_uint4(0, 0, 0, 0);
-    if (lock_on && ring_stride <= 16 && (full || is_agent)) {  // whole per-agent ring fits two 16-byte loads
-        const uint4 *rp = reinterpret_cast<const uint4 *>(io.dist_ring + ((size_t)env * N + a) * ring_stride);
-        rq0 = rp[0];
-        if (ring_stride > 8) rq1 = rp[1];
-    }
     load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     wave_lds_sync();
 #ifdef MAPF_STAMPS
@@ -1227,9 +1240,9 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
 #endif
     MAPF_STAMP(1);
     if (full && !__any(act < 0 || act > 4))
-        step_body<K, LPE, MW, true>(p, io, l, lane, env0, ngroups, act, st, sc, rq0, rq1);
+        step_body<K, LPE, MW, true>(p, io, l, lane, env0, ngroups, act, st, sc);
     else
-        step_body<K, LPE, MW, false>(p, io, l, lane, env0, ngroups, act, st, sc, rq0, rq1);
+        step_body<K, LPE, MW, false>(p, io, l, lane, env0, ngroups, act, st, sc);
 }
 
 // ------------------------------------------------------------------------------------------------

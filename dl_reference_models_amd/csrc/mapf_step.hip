@@ -384,14 +384,30 @@ int mapf_get_state(mapf_handle e, mapf_state *out) {
         HIP_TRY(e, hipMemcpy(out->counters, e->d_scal, (size_t)B * kScalInts * sizeof(int), hipMemcpyDeviceToHost));
     if (out->rng_words)
         HIP_TRY(e, hipMemcpy(out->rng_words, e->d_rng, (size_t)B * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (out->distance_ring) {  // device layout [B][N][ring_stride] -> ABI layout [B][lw][N]
+    if (out->distance_ring) {  // ABI layout [B][lw][N], slot = history row index mod lw
         const int lw = e->p.lw, rs = e->p.ring_stride;
-        std::vector<int16_t> ring(BN * rs);
-        HIP_TRY(e, hipMemcpy(ring.data(), e->d_ring, ring.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
-        for (int b = 0; b < B; b++)
-            for (int n = 0; n < N; n++)
-                for (int k = 0; k < lw; k++)
-                    out->distance_ring[((size_t)b * lw + k) * N + n] = ring[((size_t)b * N + n) * rs + k];
+        memset(out->distance_ring, 0, BN * lw * sizeof(int16_t));
+        if (lw <= 16) {  // 16 x uint8 shift register in the agent record: byte k = distance k steps ago
+            std::vector<int> scal((size_t)B * kScalInts);
+            HIP_TRY(e, hipMemcpy(scal.data(), e->d_scal, scal.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++) {
+                const int t = scal[(size_t)b * kScalInts + MAPF_CTR_HIST_ROWS];
+                for (int n = 0; n < N; n++) {
+                    const uint32_t *d = recs[(size_t)b * N + n].dist;
+                    for (int k = 0; k < lw && k < t; k++) {
+                        const int slot = ((t - 1 - k) % lw + lw) % lw;
+                        out->distance_ring[((size_t)b * lw + slot) * N + n] = (int16_t)((d[k >> 2] >> ((k & 3) * 8)) & 0xFFu);
+                    }
+                }
+            }
+        } else {  // device layout [B][N][ring_stride]
+            std::vector<int16_t> ring(BN * rs);
+            HIP_TRY(e, hipMemcpy(ring.data(), e->d_ring, ring.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++)
+                for (int n = 0; n < N; n++)
+                    for (int k = 0; k < lw; k++)
+                        out->distance_ring[((size_t)b * lw + k) * N + n] = ring[((size_t)b * N + n) * rs + k];
+        }
     }
     return MAPF_OK;
 }
@@ -402,8 +418,9 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
     const size_t BN = (size_t)B * N;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipDeviceSynchronize());
+    const bool ring_in_rec = e->p.lw <= 16;
     const bool touch_recs = in->positions || in->goals || in->starts || in->reached || in->completed_once ||
-                            in->pressure_prev || in->lock_history;
+                            in->pressure_prev || in->lock_history || (in->distance_ring && ring_in_rec);
     if (touch_recs) {
         std::vector<AgentRec> recs(BN);
         HIP_TRY(e, hipMemcpy(recs.data(), e->d_agents, BN * sizeof(AgentRec), hipMemcpyDeviceToHost));
@@ -430,13 +447,31 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
                 r.progress = in->lock_history[3 * i + 2];
             }
         }
+        if (in->distance_ring && ring_in_rec) {
+            const int lw = e->p.lw;
+            std::vector<int> scal((size_t)B * kScalInts);
+            if (in->counters) memcpy(scal.data(), in->counters, scal.size() * sizeof(int));
+            else HIP_TRY(e, hipMemcpy(scal.data(), e->d_scal, scal.size() * sizeof(int), hipMemcpyDeviceToHost));
+            for (int b = 0; b < B; b++) {
+                const int t = scal[(size_t)b * kScalInts + MAPF_CTR_HIST_ROWS];
+                for (int n = 0; n < N; n++) {
+                    uint32_t *d = recs[(size_t)b * N + n].dist;
+                    d[0] = d[1] = d[2] = d[3] = 0;
+                    for (int k = 0; k < lw && k < t; k++) {
+                        const int slot = ((t - 1 - k) % lw + lw) % lw;
+                        const uint32_t v = (uint32_t)in->distance_ring[((size_t)b * lw + slot) * N + n] & 0xFFu;
+                        d[k >> 2] |= v << ((k & 3) * 8);
+                    }
+                }
+            }
+        }
         HIP_TRY(e, hipMemcpy(e->d_agents, recs.data(), BN * sizeof(AgentRec), hipMemcpyHostToDevice));
     }
     if (in->counters)
         HIP_TRY(e, hipMemcpy(e->d_scal, in->counters, (size_t)B * kScalInts * sizeof(int), hipMemcpyHostToDevice));
     if (in->rng_words)
         HIP_TRY(e, hipMemcpy(e->d_rng, in->rng_words, (size_t)B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (in->distance_ring) {
+    if (in->distance_ring && !ring_in_rec) {
         const int lw = e->p.lw, rs = e->p.ring_stride;
         std::vector<int16_t> ring(BN * rs, 0);
         for (int b = 0; b < B; b++)
