@@ -40,7 +40,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_observe", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
+    "mapf_step", "mapf_step_many", "mapf_observe", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
 )
 
 
@@ -121,6 +121,8 @@ def load():
     L.mapf_reset.argtypes = [vp, vp, vp, vp]
     L.mapf_step.restype = C.c_int
     L.mapf_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.mapf_step_many.restype = C.c_int
+    L.mapf_step_many.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.mapf_observe.restype = C.c_int
     L.mapf_observe.argtypes = [vp, vp, vp]
     L.mapf_poll_error.restype = C.c_int

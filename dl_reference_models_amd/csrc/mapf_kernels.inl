@@ -904,7 +904,6 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
     uint4 *tabg = l.tab + grp * LPE;
     const uint64_t *myrows = l.rows + grp * H;
-    AgentRec *rec = io.agents + (size_t)env * N + a;
     const bool dist_in_rec = lw <= 16;  // goal-distance history lives in the agent record
 
     // ---- invalid action: the reference raises mid-loop, after the agents before the bad one were
@@ -1202,13 +1201,6 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
                                  sc, io.obs != nullptr);
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }
-    if (is_agent) store_lane(rec, st);
-    if (env_ok && a == 0) store_scal(io.scal, env, sc);
-    MAPF_STAMP(8);
-#ifdef MAPF_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
-#endif
-    MAPF_STAMP(9);
 }
 
 template <class K, int LPE, int MW>
@@ -1243,6 +1235,64 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
         step_body<K, LPE, MW, true>(p, io, l, lane, env0, ngroups, act, st, sc);
     else
         step_body<K, LPE, MW, false>(p, io, l, lane, env0, ngroups, act, st, sc);
+    if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (env_ok && a == 0) store_scal(io.scal, env, sc);
+    MAPF_STAMP(8);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
+#endif
+    MAPF_STAMP(9);
+}
+
+// ------------------------------------------------------------------------------------------------
+// T steps in one launch (mapf_step_many): state stays in registers, obstacle rows stay in LDS, only the
+// per-step action bytes are read and the per-step outputs written.  actions [T][B][N]; every non-null
+// output is [T][...] except obs: obs_mode 0 = none, 1 = observation after the last step only, 2 = every step.
+// Finished envs are reset inside the loop (auto_reset semantics of mapf_step).
+// ------------------------------------------------------------------------------------------------
+template <class K, int LPE, int MW>
+__global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp, const Io io, const int T,
+                                                  const int obs_mode) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Lds l = carve_lds(io, lds_raw);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G;
+    const int ngroups = min(G, io.B - env0);
+    const int N = K::N(p), L = K::L(p);
+    const bool full = ngroups == G && N == LPE;
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    const bool is_agent = env_ok && a < N;
+
+    Lane st;
+    load_lane(io.agents + (size_t)env * N + a, full || is_agent, st);
+    int sc[12];
+    load_scal(io.scal, env, sc);
+    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    wave_lds_sync();
+
+    const size_t BN = (size_t)io.B * N;
+    for (int t = 0; t < T; t++) {
+        Io it = io;
+        it.auto_reset = 1;
+        it.final_obs = nullptr;
+        it.obs = obs_mode == 2 ? io.obs + (size_t)t * BN * L : ((obs_mode == 1 && t == T - 1) ? io.obs : nullptr);
+        if (io.rewards) it.rewards = io.rewards + (size_t)t * BN;
+        if (io.terminated) it.terminated = io.terminated + (size_t)t * io.B;
+        if (io.truncated) it.truncated = io.truncated + (size_t)t * io.B;
+        if (io.info_all) it.info_all = io.info_all + (size_t)t * io.B * MAPF_INFO_ALL;
+        if (io.info_agent) it.info_agent = io.info_agent + (size_t)t * BN * 2;
+        int act = (full || is_agent) ? (int)io.actions[(size_t)t * BN + (size_t)env * N + a] : 0;
+        if (full && !__any(act < 0 || act > 4))
+            step_body<K, LPE, MW, true>(p, it, l, lane, env0, ngroups, act, st, sc);
+        else
+            step_body<K, LPE, MW, false>(p, it, l, lane, env0, ngroups, act, st, sc);
+        wave_lds_sync();  // staging / table regions are reused by the next step
+    }
+    if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (env_ok && a == 0) store_scal(io.scal, env, sc);
 }
 
 // ------------------------------------------------------------------------------------------------

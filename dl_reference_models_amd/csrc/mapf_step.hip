@@ -131,6 +131,39 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
     return hipErrorInvalidValue;
 }
 
+template <int LPE, int MW>
+hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
+    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io, T,
+                       obs_mode);
+    return hipGetLastError();
+}
+
+hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
+    switch (e->special) {
+#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
+    case ID:                                                                                                        \
+        hipLaunchKernelGGL((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),   \
+                           dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io, T, obs_mode);               \
+        return hipGetLastError();
+        MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
+#undef MAPF_LAUNCH
+    }
+#define MAPF_CASE(L)                                                               \
+    case L:                                                                        \
+        if (e->mask_w == 32) return launch_many_t<L, 32>(e, io, T, obs_mode, s);   \
+        if (e->mask_w == 64) return launch_many_t<L, 64>(e, io, T, obs_mode, s);   \
+        return launch_many_t<L, 128>(e, io, T, obs_mode, s);
+    switch (e->lpe) {
+        MAPF_CASE(4)
+        MAPF_CASE(8)
+        MAPF_CASE(16)
+        MAPF_CASE(32)
+        MAPF_CASE(64)
+    }
+#undef MAPF_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP && e->special) return launch_specialized_step(e, io, s);
 #define MAPF_CASE(L)                                                       \
@@ -550,6 +583,40 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.auto_reset = auto_reset;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
+                   uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream) {
+    if (!e || !actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
+    if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step_many");
+    Io io;
+    memset(&io, 0, sizeof io);
+    io.agents = e->d_agents;
+    io.scal = e->d_scal;
+    io.dist_ring = e->d_ring;
+    io.grid_rows = e->d_rows;
+    io.B = e->p.B;
+    io.H = e->p.H;
+    io.W = e->p.W;
+    io.eps_floor = e->p.eps_floor;
+    io.steps_per_episode = e->p.steps_per_episode;
+    io.den_r = e->p.den_r;
+    io.den_c = e->p.den_c;
+    io.lds_tab_off = e->p.lds_tab_off;
+    io.lds_stage_off = e->p.lds_stage_off;
+    io.lds_scratch_off = e->p.lds_scratch_off;
+    io.actions = actions;
+    io.obs = obs;
+    io.rewards = rewards;
+    io.terminated = terminated;
+    io.truncated = truncated;
+    io.info_all = info_all;
+    io.info_agent = info_agent;
+    io.auto_reset = 1;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, dispatch_many(e, io, T, obs_mode, (hipStream_t)stream));
     return MAPF_OK;
 }
 

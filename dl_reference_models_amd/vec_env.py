@@ -207,6 +207,38 @@ class VecReferenceModel:
             "final_obs": self._final_obs if fo is not None else None,
         }
 
+    def step_many(self, actions: torch.Tensor, obs_mode: int = 1, outputs: bool = True) -> dict:
+        """T fused steps in one launch.  actions: int8 [T,B,N] on the device.  Returns fresh tensors:
+        obs ([B,N,L] for obs_mode 1, [T,B,N,L] for 2, None for 0) and, when `outputs`, per-step rewards [T,B,N],
+        terminated / truncated [T,B], info_all [T,B,14], info_agent [T,B,N,2]."""
+        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        T = int(actions.shape[0])
+        B, N, Lo = self.num_envs, self.num_agents, self.obs_len
+        if tuple(actions.shape) != (T, B, N):
+            raise ValueError(f"actions must have shape (T, {B}, {N})")
+        dev = self.device
+        obs = None
+        if obs_mode == 1:
+            obs = torch.empty((B, N, Lo), dtype=torch.float32, device=dev)
+        elif obs_mode == 2:
+            obs = torch.empty((T, B, N, Lo), dtype=torch.float32, device=dev)
+        out = {"obs": obs, "rewards": None, "terminated": None, "truncated": None, "info_all": None, "info_agent": None}
+        if outputs:
+            out["rewards"] = torch.empty((T, B, N), dtype=torch.float32, device=dev)
+            out["terminated"] = torch.empty((T, B), dtype=torch.uint8, device=dev)
+            out["truncated"] = torch.empty((T, B), dtype=torch.uint8, device=dev)
+            out["info_all"] = torch.empty((T, B, L.INFO_ALL), dtype=torch.float32, device=dev)
+            out["info_agent"] = torch.empty((T, B, N, 2), dtype=torch.uint8, device=dev)
+
+        def ptr(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+
+        self._check(self._lib.mapf_step_many(
+            self._h, T, C.c_void_p(actions.data_ptr()), ptr(obs), int(obs_mode), ptr(out["rewards"]),
+            ptr(out["terminated"]), ptr(out["truncated"]), ptr(out["info_all"]), ptr(out["info_agent"]), self._stream()))
+        return out
+
     def observe(self) -> torch.Tensor:
         """Observation of every agent from the current state (no state change).  Returns a fresh tensor."""
         out = torch.empty_like(self._obs)

@@ -30,6 +30,8 @@
  *                         <- the private arrays callers and tests read or poke: _positions_arr, _goals_arr, _starts_arr,
  *                            _reached_arr, _completed_once_arr, _blocking_pressure_prev_arr, step_count, _episode_* counters
  *                            (MA-env:83-89, :63-69; read by src/trainers/callbacks.py:111-131,265-307 and main.py:265,314)
+ *   mapf_step_many        <- T x step() (+ reset() on done) for an action stream known up front: the loop of
+ *                                                               scripts/benchmark_multi_agent_env.py:85-95
  *   mapf_observe          <- get_obs / get_action_mask / _flatten_observation called on a static state
  *                                                               MA-env:707-773, :306-328
  *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
@@ -174,6 +176,18 @@ int mapf_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *obs /
  * the reset observation. */
 int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
               float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream);
+
+/* T consecutive steps in ONE launch (state stays in registers, obstacle rows in LDS): what the reference's
+ * env-only benchmark loop does when the actions do not depend on the observations
+ * (scripts/benchmark_multi_agent_env.py:85-95, mode "random"), or any scripted / pre-sampled action stream.
+ *   actions  device int8 [T][B][N]
+ *   obs      device float32; obs_mode 0: unused (may be NULL), 1: [B][N][L] observation after the last step,
+ *            2: [T][B][N][L] every step
+ *   rewards [T][B][N], terminated / truncated [T][B], info_all [T][B][14], info_agent [T][B][N][2]; any may be NULL
+ * Finished envs are reset inside the loop (auto_reset semantics of mapf_step: the observation of a step that
+ * ended an episode is the reset observation). */
+int mapf_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
+                   uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream);
 
 /* observation of every agent from the CURRENT state, nothing is modified: what the reference returns when
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().

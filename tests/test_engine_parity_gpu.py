@@ -246,3 +246,41 @@ def test_state_snapshot_resumes_bit_exactly_in_a_fresh_engine(extra):
         for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
             assert np.array_equal(ra[k], rb[k]), (k, t)
     assert np.array_equal(a.rng_words(), b.rng_words())
+
+
+@pytest.mark.parametrize("shape", [
+    (512, 32, 32, 8, 0.40, {}),                                                     # specialised (c3 shape)
+    (300, 16, 16, 4, 0.20, {"include_goal_distance": True}),                        # runtime-config kernel, ragged last wave
+    (32, 64, 64, 64, 0.20, {"lifelong_mapf": True, "steps_per_episode": 60}),       # lifelong, respawns + resets inside the loop
+    (40, 9, 9, 5, 0.15, {"livelock_window_steps": 30, "deadlock_window_steps": 20, "steps_per_episode": 45}),  # int16 ring path
+])
+def test_step_many_equals_repeated_single_steps(shape):
+    """mapf_step_many(T) must produce, step for step, what T mapf_step launches produce (and the same final state)."""
+    import torch
+
+    B, H, W, N, density, extra = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "steps_per_episode": 50,
+           "include_action_mask_in_obs": True}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, density, N, base_seed=120_000)
+    seeds = list(range(B))
+    T = 130
+    acts = np.random.default_rng(11).integers(0, 5, size=(T, B, N)).astype(np.int8)
+    one = EngineStepper(grids, cfg, seeds=seeds)
+    many = EngineStepper(grids, cfg, seeds=seeds)
+    one.reset()
+    many.reset()
+    fused = many.env.step_many(torch.from_numpy(acts).to(many.env.device), obs_mode=2)
+    fused = {k: v.cpu().numpy() for k, v in fused.items()}
+    for t in range(T):
+        o = one.step(acts[t], auto_reset=True)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            assert np.array_equal(o[k], fused[k][t]), (k, t)
+    sa, sb = one.env.get_state(), many.env.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    # obs_mode 1 returns only the last observation; obs_mode 0 none
+    third = EngineStepper(grids, cfg, seeds=seeds)
+    third.reset()
+    last = third.env.step_many(torch.from_numpy(acts).to(third.env.device), obs_mode=1, outputs=False)
+    assert np.array_equal(last["obs"].cpu().numpy(), fused["obs"][-1]) and last["rewards"] is None

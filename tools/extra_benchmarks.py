@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Secondary measurements quoted in DESIGN.md (not the driver's bench line): fused T-steps-per-launch throughput
+("report both"), the reference-default observation layout (mask off, L = 28), a goal-biased action
+stream (more deadlocks), and the c2 / c5 shapes.  One JSON object per line."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from dl_reference_models_amd import workloads as wl
+from dl_reference_models_amd.vec_env import VecReferenceModel
+
+
+def timed(fn, n):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3
+
+
+def run(name, over=None, fused_T=100, p=None, tag=None):
+    b, h, w, n, density, _ = wl.WORKLOADS[name]
+    cfg = wl.workload_config(name, list(range(b)))
+    cfg.update(over or {})
+    env = VecReferenceModel(cfg)
+    env.reset()
+    rng = np.random.default_rng(999)
+    pool = 100
+    if p is None:
+        a = rng.integers(0, 5, size=(pool, b, n))
+    else:
+        a = rng.choice(5, size=(pool, b, n), p=p)
+    acts = torch.from_numpy(a.astype(np.int8)).to(env.device)
+    sptr = torch.cuda.current_stream().cuda_stream
+    base, stride = acts.data_ptr(), b * n
+
+    def single():
+        for t in range(pool):
+            env.step_raw(base + t * stride, sptr, 1)
+
+    g = torch.cuda.CUDAGraph()
+    single()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        cptr = torch.cuda.current_stream().cuda_stream
+        for t in range(pool):
+            env.step_raw(base + t * stride, cptr, 1)
+    for _ in range(3):
+        g.replay()
+    dt = timed(g.replay, 10)
+    single_rate = b * n * pool * 10 / dt
+    out = {"workload": tag or name, "envs": b, "agents": n, "obs_floats": env.obs_len,
+           "specialized_kernel": env.launch_info()["specialized_kernel"],
+           "single_step_per_launch": {"agent_steps_per_s": single_rate, "us_per_step": 1e6 * dt / (pool * 10)}}
+    bytes_step = wl.algorithmic_bytes_per_env_step(n, env.obs_len, h, w) * b
+    out["single_step_per_launch"]["roofline_frac"] = bytes_step / (dt / (pool * 10)) / 8e12
+    for mode, label in ((2, "fused_obs_every_step"), (1, "fused_obs_last_only")):
+        f = lambda: env.step_many(acts[:fused_T], obs_mode=mode, outputs=True)
+        f(); f()
+        dt = timed(f, 5)
+        out[label] = {"T": fused_T, "agent_steps_per_s": b * n * fused_T * 5 / dt, "us_per_step": 1e6 * dt / (fused_T * 5)}
+        if mode == 2:
+            out[label]["roofline_frac"] = bytes_step / (dt / (fused_T * 5)) / 8e12
+    env.poll_error()
+    st = env.get_state()["counters"]
+    out["episodes_finished"] = int(st[:, 9].sum())
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    run("c3_8192x32x32_n8")
+    run("c3_8192x32x32_n8", {"include_action_mask_in_obs": False}, tag="c3 reference-default obs (mask off, L=28)")
+    run("c3_8192x32x32_n8", p=[0.1, 0.1, 0.3, 0.4, 0.1], tag="c3 goal-biased action stream")
+    run("c3_8192x32x32_n8", {"force_generic_kernel": True}, tag="c3 runtime-config kernel")
+    run("c2_1024x16x16_n4")
+    run("c5_1024x64x64_n64_lifelong")
