@@ -177,10 +177,13 @@ def main():
     per_launch_ms = np.array([a.elapsed_time(b) for a, b in samples], dtype=np.float64)
     isolated_launch_ms = float(np.median(per_launch_ms)) if len(per_launch_ms) else None
 
-    # off the timed path: optional RCCL sum of episode statistics (64-byte message, latency-bound)
-    st = env.get_state()["counters"]
-    stats = np.array([float(st[:, 9].sum())], dtype=np.float64)
-    stats = sharding.all_reduce_stats(stats, device=device if use_dist else None)
+    # off the timed path: episode statistics accumulated on the device, summed over ranks with ONE small
+    # RCCL all-reduce (96 bytes; latency-bound, so one fused buffer)
+    from dl_reference_models_amd.vec_env import metrics_from_sums
+
+    sums = sharding.all_reduce_stats(env.episode_sums().astype(np.float64), device=device if use_dist else None)
+    stats = [float(sums[0])]
+    episode_metrics = metrics_from_sums(sums, n, bool(cfg.get("lifelong_mapf", False)))
 
     agent_steps = b_per * n * args.steps * world
     bytes_per_launch = wl.algorithmic_bytes_per_env_step(n, L, h, w) * b_per
@@ -221,6 +224,7 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
         "episodes_finished": float(stats[0]),
+        "episode_metrics": episode_metrics,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

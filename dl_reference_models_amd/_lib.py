@@ -34,13 +34,17 @@ CTR_STEP_COUNT, CTR_HIST_ROWS, CTR_BLOCKING_COUNT, CTR_GOALS_REACHED_TOTAL = 0, 
 CTR_DEADLOCK_EVENTS, CTR_LIVELOCK_EVENTS, CTR_DEADLOCK_STEPS, CTR_LIVELOCK_STEPS = 4, 5, 6, 7
 CTR_LOCK_STATE_PREV, CTR_EPISODES_DONE = 8, 9
 
+NUM_EPISODE_ACC = 12
+(ACC_EPISODES, ACC_SUCCESSES, ACC_GOALS_REACHED, ACC_BLOCKING_COUNT, ACC_DEADLOCK_COUNT, ACC_LIVELOCK_COUNT,
+ ACC_DEADLOCK_STEPS, ACC_LIVELOCK_STEPS, ACC_COMPLETED_AGENTS, ACC_EPISODE_STEPS) = range(10)
+
 MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 
 # every symbol include/mapf_step.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_many", "mapf_observe", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
+    "mapf_step", "mapf_step_many", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
 )
 
 
@@ -125,6 +129,8 @@ def load():
     L.mapf_step_many.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.mapf_observe.restype = C.c_int
     L.mapf_observe.argtypes = [vp, vp, vp]
+    L.mapf_get_episode_stats.restype = C.c_int
+    L.mapf_get_episode_stats.argtypes = [vp, vp, i32]
     L.mapf_poll_error.restype = C.c_int
     L.mapf_poll_error.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.mapf_debug_stamps.restype = C.c_int

@@ -62,6 +62,7 @@ struct Params {
     const uint16_t *free_rank;   // [B][HW], row-major rank of a free cell among free cells
     const int *n_free;           // [B]
     int *err;                    // [4] code, env, agent, value
+    int *ep_acc;                 // [B][MAPF_NUM_EPISODE_ACC] lifetime per-env sums over finished episodes
     unsigned long long *dbg;     // diagnostic build only (-DMAPF_STAMPS): [blocks][16] s_memtime stamps
 };
 
@@ -1190,6 +1191,29 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (pressure_prev ? kFlagPressure : 0);
     } else {
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+    }
+
+    // ---- episode statistics (what the reference's RLlib callbacks read from the env when an episode ends,
+    //      src/trainers/callbacks.py:236-345): per-env lifetime sums, touched only on the finishing step ----
+    if (__any(done)) {
+        const int completed_now = __popcll(gballot<LPE>(is_agent && completed, lane));
+        if (done && a == 0) {
+            int4 *acc = reinterpret_cast<int4 *>(p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC);
+            int4 q0 = acc[0], q1 = acc[1], q2 = acc[2];
+            q0.x += 1;                                      // MAPF_ACC_EPISODES
+            q0.y += (term && !trunc) ? 1 : 0;               // MAPF_ACC_SUCCESSES (SuccessRateCallback)
+            q0.z += sc[MAPF_CTR_GOALS_REACHED_TOTAL];       // goals_reached  <- _episode_goals_reached_total
+            q0.w += sc[MAPF_CTR_BLOCKING_COUNT];            // blocking_count <- _episode_blocking_count
+            q1.x += sc[MAPF_CTR_DEADLOCK_EVENTS];           // deadlock_count
+            q1.y += sc[MAPF_CTR_LIVELOCK_EVENTS];           // livelock_count
+            q1.z += sc[MAPF_CTR_DEADLOCK_STEPS];
+            q1.w += sc[MAPF_CTR_LIVELOCK_STEPS];
+            q2.x += completed_now;                          // completion_ratio numerator (_completed_once_arr)
+            q2.y += sc[MAPF_CTR_STEP_COUNT];                // episode length
+            acc[0] = q0;
+            acc[1] = q1;
+            acc[2] = q2;
+        }
     }
 
     // ---- auto-reset of finished envs (reference harness loop scripts/benchmark_multi_agent_env.py:89-95:

@@ -68,6 +68,7 @@ struct mapf_engine {
     uint16_t *d_free_rank = nullptr;
     int *d_n_free = nullptr;
     int *d_err = nullptr;
+    int *d_ep_acc = nullptr;
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
 };
@@ -311,6 +312,9 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMemset(e->d_ring, 0, BN * p.ring_stride * sizeof(int16_t)));
     HIP_TRY(e, hipMemset(e->d_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMemset(e->d_err, 0, 4 * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_ep_acc, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
+    HIP_TRY(e, hipMemset(e->d_ep_acc, 0, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
+    p.ep_acc = e->d_ep_acc;
     p.rng = e->d_rng;
     p.free_cells = e->d_free_cells;
     p.free_rank = e->d_free_rank;
@@ -338,6 +342,7 @@ int mapf_destroy(mapf_handle e) {
     hipFree(e->d_free_rank);
     hipFree(e->d_n_free);
     hipFree(e->d_err);
+    hipFree(e->d_ep_acc);
     hipFree(e->d_params);
     hipFree(e->d_dbg);
     delete e;
@@ -642,6 +647,19 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.obs = obs;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+int mapf_get_episode_stats(mapf_handle e, int64_t *out, int32_t reset) {
+    if (!e || !out) return fail(e, MAPF_ERR_CONFIG, "null argument");
+    const size_t n = (size_t)e->p.B * MAPF_NUM_EPISODE_ACC;
+    std::vector<int> acc(n);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(acc.data(), e->d_ep_acc, n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int k = 0; k < MAPF_NUM_EPISODE_ACC; k++) out[k] = 0;
+    for (size_t i = 0; i < n; i++) out[i % MAPF_NUM_EPISODE_ACC] += acc[i];
+    if (reset) HIP_TRY(e, hipMemset(e->d_ep_acc, 0, n * sizeof(int)));
     return MAPF_OK;
 }
 

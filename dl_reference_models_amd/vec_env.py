@@ -44,6 +44,32 @@ def pcg64_words(seed) -> np.ndarray:
     return np.array([s >> 64, s & m, inc >> 64, inc & m, int(st["has_uint32"]), int(st["uinteger"])], dtype=np.uint64)
 
 
+def metrics_from_sums(s, num_agents: int, lifelong: bool) -> dict:
+    """Means over finished episodes from the int64 accumulator vector (exact rational arithmetic in float64)."""
+    n = float(s[L.ACC_EPISODES])
+    if n == 0:
+        return {"episodes": 0}
+    m = {
+        "episodes": int(s[L.ACC_EPISODES]),
+        "goals_reached": s[L.ACC_GOALS_REACHED] / n,
+        "blocking_count": s[L.ACC_BLOCKING_COUNT] / n,
+        "deadlock_count": s[L.ACC_DEADLOCK_COUNT] / n,
+        "livelock_count": s[L.ACC_LIVELOCK_COUNT] / n,
+        "deadlock_steps": s[L.ACC_DEADLOCK_STEPS] / n,
+        "livelock_steps": s[L.ACC_LIVELOCK_STEPS] / n,
+        "episode_len_mean": s[L.ACC_EPISODE_STEPS] / n,
+    }
+    completion = s[L.ACC_COMPLETED_AGENTS] / (n * num_agents)
+    if lifelong:  # SuccessRateCallback logs the completion ratio as success in lifelong mode (callbacks.py:150-155)
+        m["success_rate"] = completion
+        m["completion_ratio"] = completion
+        # every lifelong episode runs to the step limit, so the mean of goals/steps is the ratio of the sums
+        m["throughput"] = s[L.ACC_GOALS_REACHED] / max(float(s[L.ACC_EPISODE_STEPS]), 1.0)
+    else:
+        m["success_rate"] = s[L.ACC_SUCCESSES] / n
+    return m
+
+
 def config_flags(cfg: dict) -> int:
     f = 0
     if cfg.get("normalize_goal_delta", True):
@@ -251,6 +277,19 @@ class VecReferenceModel:
             self._h, actions_ptr, self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(),
             self._truncated.data_ptr(), self._info_all.data_ptr(), self._info_agent.data_ptr(), None, auto_reset,
             stream_ptr)
+
+    def episode_sums(self, reset: bool = False) -> np.ndarray:
+        """int64[12] sums over all finished episodes of all envs (columns: _lib.ACC_*)."""
+        out = np.zeros(L.NUM_EPISODE_ACC, dtype=np.int64)
+        self._check(self._lib.mapf_get_episode_stats(self._h, out.ctypes.data_as(C.c_void_p), 1 if reset else 0))
+        return out
+
+    def episode_metrics(self, reset: bool = False, sums: np.ndarray | None = None) -> dict:
+        """Mean per-episode metrics under the names the reference's RLlib callbacks log
+        (src/trainers/callbacks.py: success_rate :138-181, goals_reached ... livelock_steps :325-330,
+        throughput / completion_ratio :331-335).  `sums` lets a multi-GPU job pass the all-reduced vector."""
+        return metrics_from_sums(self.episode_sums(reset) if sums is None else sums, self.num_agents,
+                                 self.lifelong_mapf)
 
     def poll_error(self):
         """Synchronize and raise the Python exception the reference would have raised inside step()."""

@@ -32,6 +32,7 @@
  *                            (MA-env:83-89, :63-69; read by src/trainers/callbacks.py:111-131,265-307 and main.py:265,314)
  *   mapf_step_many        <- T x step() (+ reset() on done) for an action stream known up front: the loop of
  *                                                               scripts/benchmark_multi_agent_env.py:85-95
+ *   mapf_get_episode_stats <- what ReferenceModelCallbacks.on_episode_end reads from the env   src/trainers/callbacks.py:236-345
  *   mapf_observe          <- get_obs / get_action_mask / _flatten_observation called on a static state
  *                                                               MA-env:707-773, :306-328
  *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
@@ -102,6 +103,20 @@ extern "C" {
 #define MAPF_CTR_LIVELOCK_STEPS 7
 #define MAPF_CTR_LOCK_STATE_PREV 8      /* bit0 _deadlock_state_prev, bit1 _livelock_state_prev MA-env:68-69 */
 #define MAPF_CTR_EPISODES_DONE 9        /* episodes finished by this env since create (auto-reset bookkeeping) */
+
+/* per-env lifetime sums over finished episodes, mapf_get_episode_stats() adds them up over the envs:
+ * the quantities the reference's RLlib callbacks log at episode end (src/trainers/callbacks.py:135-345) */
+#define MAPF_NUM_EPISODE_ACC 12
+#define MAPF_ACC_EPISODES 0
+#define MAPF_ACC_SUCCESSES 1        /* terminated and not truncated (SuccessRateCallback, finite mode) */
+#define MAPF_ACC_GOALS_REACHED 2    /* sum of _episode_goals_reached_total at episode end */
+#define MAPF_ACC_BLOCKING_COUNT 3
+#define MAPF_ACC_DEADLOCK_COUNT 4   /* rising-edge events */
+#define MAPF_ACC_LIVELOCK_COUNT 5
+#define MAPF_ACC_DEADLOCK_STEPS 6
+#define MAPF_ACC_LIVELOCK_STEPS 7
+#define MAPF_ACC_COMPLETED_AGENTS 8 /* agents with _completed_once_arr set at episode end (completion_ratio numerator) */
+#define MAPF_ACC_EPISODE_STEPS 9    /* sum of step_count at episode end */
 
 typedef struct mapf_config {
     int32_t num_envs;           /* B >= 1 */
@@ -193,6 +208,11 @@ int mapf_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, 
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().
  * obs: device float32 [B][N][L]. */
 int mapf_observe(mapf_handle h, float *obs /* device */, void *stream);
+
+/* sums of the per-env episode accumulators over all envs of the handle: host int64 out[MAPF_NUM_EPISODE_ACC];
+ * reset != 0 clears them afterwards.  Synchronizes the device.  (Off the hot path; for a multi-GPU job add the
+ * vectors of the ranks, e.g. one RCCL all-reduce of this 96-byte buffer per reporting interval.) */
+int mapf_get_episode_stats(mapf_handle h, int64_t *out /* host */, int32_t reset);
 
 /* read (and clear) the device error record; synchronizes `stream`.  Returns MAPF_OK when no env has
  * failed, else the code of the first failure with its env / agent / offending value. */

@@ -284,3 +284,61 @@ def test_step_many_equals_repeated_single_steps(shape):
     third.reset()
     last = third.env.step_many(torch.from_numpy(acts).to(third.env.device), obs_mode=1, outputs=False)
     assert np.array_equal(last["obs"].cpu().numpy(), fused["obs"][-1]) and last["rewards"] is None
+
+
+@pytest.mark.parametrize("lifelong", [False, True])
+def test_episode_metrics_match_what_the_callbacks_would_log(lifelong):
+    """Device-side episode accumulators vs the same sums taken from the ORACLE's outputs at every episode end,
+    using the definitions of the reference's callbacks (src/trainers/callbacks.py:138-181, :236-335)."""
+    from dl_reference_models_amd._lib import (ACC_BLOCKING_COUNT, ACC_COMPLETED_AGENTS, ACC_DEADLOCK_COUNT, ACC_DEADLOCK_STEPS,
+                                              ACC_EPISODES, ACC_EPISODE_STEPS, ACC_GOALS_REACHED, ACC_LIVELOCK_COUNT,
+                                              ACC_LIVELOCK_STEPS, ACC_SUCCESSES)
+
+    B, N = 96, 4
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 1, "steps_per_episode": 35, "lifelong_mapf": lifelong}
+    grids = synth_grids(B, 6, 6, 0.10, N, base_seed=130_000)
+    seeds = list(range(B))
+    eng, orc_ = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    eng.reset()
+    orc_.reset()
+    rng = np.random.default_rng(21)
+    want = np.zeros(12, dtype=np.int64)
+    steps_in_ep = np.zeros(B, dtype=np.int64)
+    for t in range(200):
+        # mostly greedy actions so that finite episodes also END IN SUCCESS sometimes
+        pos, goals = orc_.positions().astype(int), orc_.goals().astype(int)
+        d = goals - pos
+        greedy = np.where(np.abs(d[..., 0]) >= np.abs(d[..., 1]), np.where(d[..., 0] > 0, 3, np.where(d[..., 0] < 0, 1, 0)),
+                          np.where(d[..., 1] > 0, 2, 4))
+        acts = np.where(rng.random((B, N)) < 0.8, greedy, rng.integers(0, 5, size=(B, N))).astype(np.int8)
+        ro, re = orc_.step(acts), eng.step(acts)
+        assert np.array_equal(ro["info_all"], re["info_all"]) and np.array_equal(ro["terminated"], re["terminated"])
+        steps_in_ep += 1
+        done = (ro["terminated"] | ro["truncated"]).astype(bool)
+        ia = ro["info_all"][done]
+        want[ACC_EPISODES] += done.sum()
+        want[ACC_SUCCESSES] += (ro["terminated"].astype(bool) & ~ro["truncated"].astype(bool)).sum()
+        # at episode end info_all holds the episode totals the callbacks read from the env attributes;
+        # _episode_goals_reached_total equals goals_reached_total in both modes (first arrivals are counted once)
+        want[ACC_GOALS_REACHED] += int(ia[:, 1].sum())
+        want[ACC_BLOCKING_COUNT] += int(ia[:, 3].sum())
+        want[ACC_DEADLOCK_COUNT] += int(ia[:, 8].sum())
+        want[ACC_LIVELOCK_COUNT] += int(ia[:, 9].sum())
+        want[ACC_DEADLOCK_STEPS] += int(ia[:, 10].sum())
+        want[ACC_LIVELOCK_STEPS] += int(ia[:, 11].sum())
+        want[ACC_COMPLETED_AGENTS] += int(np.rint(ia[:, 12] * N).sum())
+        want[ACC_EPISODE_STEPS] += int(steps_in_ep[done].sum())
+        steps_in_ep[done] = 0
+    got = eng.env.episode_sums()
+    assert np.array_equal(got, want), (got, want)
+    assert want[ACC_EPISODES] >= 5 * B
+    m = eng.env.episode_metrics()
+    assert m["episodes"] == want[ACC_EPISODES] and m["goals_reached"] == want[ACC_GOALS_REACHED] / want[ACC_EPISODES]
+    if lifelong:
+        assert want[ACC_SUCCESSES] == 0 and m["episode_len_mean"] == 35.0
+        assert m["success_rate"] == m["completion_ratio"] == want[ACC_COMPLETED_AGENTS] / (want[ACC_EPISODES] * N)
+        assert m["throughput"] == pytest.approx(want[ACC_GOALS_REACHED] / want[ACC_EPISODE_STEPS])
+    else:
+        assert want[ACC_SUCCESSES] > 0 and m["success_rate"] == want[ACC_SUCCESSES] / want[ACC_EPISODES]
+        assert "throughput" not in m
+    assert np.array_equal(eng.env.episode_sums(reset=True), want) and eng.env.episode_sums().sum() == 0
