@@ -551,6 +551,80 @@ def g9_benchmark_pin():
     print(f"  g9_benchmark_pin.npz episodes_completed={episodes}")
 
 
+def record_cte_trace(cfg: dict, grids, seeds, T: int, greedy: float, action_seed: int = 77) -> dict:
+    """Single-agent (CTE) sibling env (reference reference_model_single_agent.py): B envs in lockstep."""
+    B, N = len(seeds), int(cfg["num_agents"])
+    envs, words = [], []
+    for b in range(B):
+        words.append(pcg_words(np.random.default_rng(int(seeds[b])).bit_generator.state))
+        envs.append(rh.make_reference_single_agent_env(dict(cfg, seed=int(seeds[b])), None if grids is None else grids[b]))
+    L = int(envs[0].observation_space.shape[0])
+    rng = np.random.default_rng(action_seed)
+    pos = lambda e, d: np.array([d[f"agent_{i}"] for i in range(N)], np.int16)
+    out = {
+        "config": np.array(json.dumps(cfg)), "grids": np.stack([e.grid for e in envs]).astype(np.uint8),
+        "rng_words": np.stack(words), "seeds": np.asarray(seeds, np.int64),
+        "ctor_starts": np.stack([pos(e, e.starts) for e in envs]), "ctor_goals": np.stack([pos(e, e.goals) for e in envs]),
+        "actions": np.zeros((T, B, N), np.int8), "obs": np.zeros((T, B, L), np.float32),
+        "reward": np.zeros((T, B), np.float64), "terminated": np.zeros((T, B), np.uint8),
+        "truncated": np.zeros((T, B), np.uint8), "info": np.zeros((T, B, 4), np.float32),
+        "positions": np.zeros((T, B, N, 2), np.int16), "did_reset": np.zeros((T, B), np.uint8),
+        "reset_obs": np.zeros((T, B, L), np.float32), "reset0_obs": np.zeros((B, L), np.float32),
+        "reset0_positions": np.zeros((B, N, 2), np.int16), "reset0_goals": np.zeros((B, N, 2), np.int16),
+        "final_rng_words": np.zeros((B, 6), np.uint64),
+    }
+    for b, e in enumerate(envs):
+        o, info = e.reset()
+        out["reset0_obs"][b] = o
+        out["reset0_positions"][b] = pos(e, e.positions)
+        out["reset0_goals"][b] = pos(e, e.goals)
+        assert np.array_equal(info["action_mask"].astype(np.float32), o[-5 * N:])
+    for t in range(T):
+        for b, e in enumerate(envs):
+            acts = rng.integers(0, 5, size=N)
+            for a in range(N):
+                if rng.random() < greedy:
+                    d = np.asarray(e.goals[f"agent_{a}"], int) - np.asarray(e.positions[f"agent_{a}"], int)
+                    if abs(d[0]) >= abs(d[1]) and d[0] != 0:
+                        acts[a] = 3 if d[0] > 0 else 1
+                    elif d[1] != 0:
+                        acts[a] = 2 if d[1] > 0 else 4
+            out["actions"][t, b] = acts
+            o, r, term, trunc, info = e.step([int(x) for x in acts])
+            out["obs"][t, b] = o
+            out["reward"][t, b] = r
+            out["terminated"][t, b], out["truncated"][t, b] = term, trunc
+            out["info"][t, b] = [info["blocking_count_step"], info["goals_reached_step"], info["goals_reached_total"],
+                                 info["blocking_count_total"]]
+            out["positions"][t, b] = pos(e, e.positions)
+            if term or trunc:
+                o, _ = e.reset()
+                out["did_reset"][t, b] = 1
+                out["reset_obs"][t, b] = o
+    for b, e in enumerate(envs):
+        out["final_rng_words"][b] = pcg_words(e.rng.bit_generator.state)
+    return out
+
+
+def gs_single_agent_traces():
+    cfg = {"env_name": "ReferenceModel-2-1", "num_agents": 4, "steps_per_episode": 60, "deterministic": True}
+    tr = record_cte_trace(cfg, None, [123], 250, greedy=0.7)
+    save("gs_cte_named_2_1_det", tr)
+    cfg = {"env_name": "ReferenceModel-2-2", "num_agents": 4, "steps_per_episode": 50}
+    save("gs_cte_named_2_2", record_cte_trace(cfg, None, [5, 6], 220, greedy=0.8))
+    cfg = {"env_name": "synthetic", "num_agents": 5, "steps_per_episode": 40, "blocking_penalty": -0.3,
+           "move_after_goal_penalty": -0.07}
+    grids = [synth_grid(70_000 + b, 6, 7, 0.20, 10) for b in range(6)]
+    tr = record_cte_trace(cfg, grids, list(range(6)), 400, greedy=0.8)
+    succ = int((tr["terminated"].astype(bool) & ~tr["truncated"].astype(bool)).sum())
+    print(f"  gs small: blocking={tr['info'][:, :, 0].sum():.0f} goals={tr['info'][:, :, 1].sum():.0f} successes={succ}")
+    assert tr["info"][:, :, 0].sum() >= 10 and succ >= 1
+    save("gs_cte_6x7_n5_penalties", tr)
+    cfg = {"env_name": "synthetic", "num_agents": 8, "steps_per_episode": 100}
+    grids = [synth_grid(10_000 + b, 16, 16, 0.20, 16) for b in range(4)]
+    save("gs_cte_16x16_n8", record_cte_trace(cfg, grids, list(range(4)), 250, greedy=0.3))
+
+
 def export_named_grids():
     """Named-grid data (get_grid.py:17-857 tables) -> package data file, via the reference's own accessors."""
     _, gg = rh.load_reference()
@@ -583,6 +657,7 @@ def main():
     g5_error_paths()
     g6_rng_known_answers()
     g9_benchmark_pin()
+    gs_single_agent_traces()
     sizes = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
     print(f"total golden size: {sizes / 1024:.0f} KiB")
 

@@ -19,6 +19,13 @@ enum { EMPTY_CELL = 0, OBSTACLE_CELL = 1, OTHER_AGENT_CELL = 2, OWN_GOAL_CELL = 
 /* MA-env:104-113 / actions.py:1-5: NO_OP, UP, RIGHT, DOWN, LEFT as (d_row, d_col) */
 static const int ACTION_DELTAS[5][2] = {{0, 0}, {-1, 0}, {0, 1}, {1, 0}, {0, -1}};
 
+/* numpy Generator(PCG64) state */
+typedef struct mo_rng {
+    u128 rng_state, rng_inc;
+    int32_t has_uint32;
+    uint32_t uinteger;
+} mo_rng;
+
 struct mo_env {
     mo_config cfg;
     int H, W, N, V, L, Hs;
@@ -44,10 +51,7 @@ struct mo_env {
     uint8_t *moved_flags, *failed_move_flags, *goal_progress_flags, *prev_on_goal, *current_on_goal;
     int16_t *distance_to_goal;
     int *participants; /* [N][N+1]: count + members */
-    /* numpy PCG64 */
-    u128 rng_state, rng_inc;
-    int32_t has_uint32;
-    uint32_t uinteger;
+    mo_rng rng; /* numpy PCG64 */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -56,7 +60,7 @@ struct mo_env {
 #define PCG_MULT_HI 0x2360ED051FC65DA4ULL
 #define PCG_MULT_LO 0x4385DF649FCCF645ULL
 
-static uint64_t pcg64_next64(mo_env *e) {
+static uint64_t pcg64_next64(mo_rng *e) {
     /* pcg64.h: pcg_setseq_128_step_r then pcg_output_xsl_rr_128_64 on the NEW state */
     const u128 mult = ((u128)PCG_MULT_HI << 64) | PCG_MULT_LO;
     e->rng_state = e->rng_state * mult + e->rng_inc;
@@ -66,7 +70,7 @@ static uint64_t pcg64_next64(mo_env *e) {
     return (x >> rot) | (x << ((-rot) & 63));
 }
 
-static uint32_t pcg64_next32(mo_env *e) {
+static uint32_t pcg64_next32(mo_rng *e) {
     /* pcg64.h pcg64_next32: hand out the low half first, cache the high half */
     if (e->has_uint32) {
         e->has_uint32 = 0;
@@ -80,7 +84,7 @@ static uint32_t pcg64_next32(mo_env *e) {
 
 /* distributions.c random_bounded_uint64(off=0, rng, mask, use_masked=false), 32-bit branch only:
  * every call site on this path has rng < 2^32 - 1 (rng <= free cells <= 4096). */
-static uint64_t rng_bounded(mo_env *e, uint64_t rng) {
+static uint64_t rng_bounded(mo_rng *e, uint64_t rng) {
     if (rng == 0) return 0; /* no draw */
     if (rng == 0xFFFFFFFFu) return pcg64_next32(e);
     /* buffered_bounded_lemire_uint32 */
@@ -99,7 +103,7 @@ static uint64_t rng_bounded(mo_env *e, uint64_t rng) {
 
 /* _generator.pyx Generator.choice(pop, size, replace=False), p=None, shuffle=True: Floyd branch.
  * (The tail-shuffle branch needs pop > 10000, impossible for grids up to 64x64 = 4096 cells.) */
-static void rng_choice_noreplace(mo_env *e, int64_t pop, int64_t size, int64_t *out) {
+static void rng_choice_noreplace(mo_rng *e, int64_t pop, int64_t size, int64_t *out) {
     uint64_t set_size = (uint64_t)(1.2 * (double)size);
     uint64_t mask = set_size; /* _gen_mask: smear to 2^p - 1 */
     mask |= mask >> 1;
@@ -135,27 +139,34 @@ static void rng_choice_noreplace(mo_env *e, int64_t pop, int64_t size, int64_t *
     free(hash_set);
 }
 
-uint64_t mo_rng_bounded(mo_env *e, uint64_t rng_inclusive) { return rng_bounded(e, rng_inclusive); }
+uint64_t mo_rng_bounded(mo_env *e, uint64_t rng_inclusive) { return rng_bounded(&e->rng, rng_inclusive); }
 void mo_rng_choice_noreplace(mo_env *e, int64_t pop, int64_t size, int64_t *out) {
-    rng_choice_noreplace(e, pop, size, out);
+    rng_choice_noreplace(&e->rng, pop, size, out);
+}
+
+static void rng_set(mo_rng *g, uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo, int32_t has_uint32,
+                    uint32_t uinteger) {
+    g->rng_state = ((u128)state_hi << 64) | state_lo;
+    g->rng_inc = ((u128)inc_hi << 64) | inc_lo;
+    g->has_uint32 = has_uint32;
+    g->uinteger = uinteger;
+}
+
+static void rng_get(const mo_rng *g, uint64_t out[6]) {
+    out[0] = (uint64_t)(g->rng_state >> 64);
+    out[1] = (uint64_t)g->rng_state;
+    out[2] = (uint64_t)(g->rng_inc >> 64);
+    out[3] = (uint64_t)g->rng_inc;
+    out[4] = (uint64_t)g->has_uint32;
+    out[5] = (uint64_t)g->uinteger;
 }
 
 void mo_set_rng(mo_env *e, uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo, int32_t has_uint32,
                 uint32_t uinteger) {
-    e->rng_state = ((u128)state_hi << 64) | state_lo;
-    e->rng_inc = ((u128)inc_hi << 64) | inc_lo;
-    e->has_uint32 = has_uint32;
-    e->uinteger = uinteger;
+    rng_set(&e->rng, state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger);
 }
 
-void mo_get_rng(const mo_env *e, uint64_t out[6]) {
-    out[0] = (uint64_t)(e->rng_state >> 64);
-    out[1] = (uint64_t)e->rng_state;
-    out[2] = (uint64_t)(e->rng_inc >> 64);
-    out[3] = (uint64_t)e->rng_inc;
-    out[4] = (uint64_t)e->has_uint32;
-    out[5] = (uint64_t)e->uinteger;
-}
+void mo_get_rng(const mo_env *e, uint64_t out[6]) { rng_get(&e->rng, out); }
 
 /* ------------------------------------------------------------------------------------------
  * construction, MA-env:34-184
@@ -325,7 +336,7 @@ int mo_generate_starts_goals(mo_env *e) {
     int N = e->N, required = 2 * N;
     if (e->n_free < required) return MO_ERR_FEW_FREE; /* :270-275 */
     int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * required);
-    rng_choice_noreplace(e, e->n_free, required, idx); /* :277 */
+    rng_choice_noreplace(&e->rng, e->n_free, required, idx); /* :277 */
     for (int i = 0; i < N; i++) {
         e->starts[2 * i] = e->free_positions[2 * idx[i]];
         e->starts[2 * i + 1] = e->free_positions[2 * idx[i] + 1];
@@ -358,7 +369,7 @@ int mo_assign_new_goal(mo_env *e, int a) {
         if (OWN(e, occupancy_owner, r, c) == UNASSIGNED_OWNER && OWN(e, goal_owner, r, c) == UNASSIGNED_OWNER) k++;
     }
     if (k == 0) return MO_ERR_NO_RESPAWN; /* :296-298 */
-    int64_t sel = (int64_t)rng_bounded(e, (uint64_t)(k - 1)); /* rng.integers(k), :300 */
+    int64_t sel = (int64_t)rng_bounded(&e->rng, (uint64_t)(k - 1)); /* rng.integers(k), :300 */
     int seen = 0;
     for (int f = 0; f < e->n_free; f++) {
         int r = e->free_positions[2 * f], c = e->free_positions[2 * f + 1];
@@ -818,4 +829,218 @@ int mo_batch_step(mo_batch *b, const int8_t *actions, int auto_reset, float *obs
         }
     }
     return first_err;
+}
+
+/* ==========================================================================================
+ * Single-agent (CTE) sibling env: /root/reference/src/environments/reference_model_single_agent.py
+ * ("SA-env:N").  One policy controls all agents; full-grid observation; scalar reward.
+ * Restates __init__ state :84-114, generate_starts_goals :158-191, reset :222-244, step :246-363,
+ * get_obs :407-441, get_action_mask :443-495.  Pinned by golden traces recorded from the reference
+ * (tests/golden/gs_*.npz) -- the reference's own tests only check dtype/bounds for this env.
+ * ========================================================================================== */
+struct moc_env {
+    int H, W, N, steps_per_episode, deterministic;
+    double blocking_penalty, move_after_goal_penalty; /* SA-env:92-93 */
+    uint8_t *grid;
+    int16_t *free_positions;
+    int n_free;
+    int32_t *starts, *positions, *goals; /* [N][2] */
+    uint8_t *reached_once;               /* goal_reached_once SA-env:91 */
+    int32_t step_count;
+    double episode_blocking_count;
+    mo_rng rng;
+};
+
+moc_env *moc_create(int H, int W, int N, int steps_per_episode, int deterministic, double blocking_penalty,
+                    double move_after_goal_penalty, const uint8_t *grid) {
+    if (H < 1 || W < 1 || N < 1 || N > 4096) return NULL;
+    moc_env *e = (moc_env *)calloc(1, sizeof(moc_env));
+    e->H = H; e->W = W; e->N = N;
+    e->steps_per_episode = steps_per_episode;
+    e->deterministic = deterministic;
+    e->blocking_penalty = blocking_penalty;
+    e->move_after_goal_penalty = move_after_goal_penalty;
+    e->grid = (uint8_t *)malloc((size_t)H * W);
+    memcpy(e->grid, grid, (size_t)H * W);
+    e->free_positions = (int16_t *)malloc(sizeof(int16_t) * 2 * H * W);
+    for (int r = 0; r < H; r++)
+        for (int c = 0; c < W; c++)
+            if (grid[r * W + c] == 0) { /* np.argwhere(self.grid == 0) SA-env:171 */
+                e->free_positions[2 * e->n_free] = (int16_t)r;
+                e->free_positions[2 * e->n_free + 1] = (int16_t)c;
+                e->n_free++;
+            }
+    e->starts = (int32_t *)calloc(2 * N, sizeof(int32_t));
+    e->positions = (int32_t *)calloc(2 * N, sizeof(int32_t));
+    e->goals = (int32_t *)calloc(2 * N, sizeof(int32_t));
+    e->reached_once = (uint8_t *)calloc(N, 1);
+    return e;
+}
+
+void moc_destroy(moc_env *e) {
+    if (!e) return;
+    free(e->grid); free(e->free_positions); free(e->starts); free(e->positions); free(e->goals); free(e->reached_once);
+    free(e);
+}
+
+int moc_obs_len(const moc_env *e) { return e->H * e->W + 5 * e->N; } /* SA-env:124-141 */
+
+void moc_set_rng(moc_env *e, uint64_t a, uint64_t b, uint64_t c, uint64_t d, int32_t has32, uint32_t u) {
+    rng_set(&e->rng, a, b, c, d, has32, u);
+}
+void moc_get_rng(const moc_env *e, uint64_t out[6]) { rng_get(&e->rng, out); }
+
+void moc_set_fixed_starts_goals(moc_env *e, const int32_t *starts, const int32_t *goals) { /* SA-env:109-112 */
+    memcpy(e->starts, starts, sizeof(int32_t) * 2 * e->N);
+    memcpy(e->positions, starts, sizeof(int32_t) * 2 * e->N);
+    memcpy(e->goals, goals, sizeof(int32_t) * 2 * e->N);
+}
+
+/* SA-env:158-191: one rng.choice(F) (= integers(0, F)) per attempt, rejection until unique */
+void moc_generate_starts_goals(moc_env *e) {
+    const int N = e->N;
+    for (int i = 0; i < N; i++) {
+        for (;;) {
+            int idx = (int)rng_bounded(&e->rng, (uint64_t)(e->n_free - 1));
+            int r = e->free_positions[2 * idx], c = e->free_positions[2 * idx + 1];
+            int clash = 0;
+            for (int j = 0; j < i; j++) clash |= (e->starts[2 * j] == r && e->starts[2 * j + 1] == c);
+            if (!clash) {
+                e->starts[2 * i] = r;
+                e->starts[2 * i + 1] = c;
+                break;
+            }
+        }
+    }
+    memcpy(e->positions, e->starts, sizeof(int32_t) * 2 * N);
+    for (int i = 0; i < N; i++) {
+        for (;;) {
+            int idx = (int)rng_bounded(&e->rng, (uint64_t)(e->n_free - 1));
+            int r = e->free_positions[2 * idx], c = e->free_positions[2 * idx + 1];
+            int clash = 0;
+            for (int j = 0; j < i; j++) clash |= (e->goals[2 * j] == r && e->goals[2 * j + 1] == c);
+            for (int j = 0; j < N; j++) clash |= (e->starts[2 * j] == r && e->starts[2 * j + 1] == c);
+            if (!clash) {
+                e->goals[2 * i] = r;
+                e->goals[2 * i + 1] = c;
+                break;
+            }
+        }
+    }
+}
+
+static void moc_observe(const moc_env *e, float *out) {
+    const int H = e->H, W = e->W, N = e->N;
+    uint8_t *obs = (uint8_t *)malloc((size_t)H * W);
+    memcpy(obs, e->grid, (size_t)H * W);                                                    /* SA-env:427 */
+    for (int i = 0; i < N; i++) obs[e->goals[2 * i] * W + e->goals[2 * i + 1]] = (uint8_t)(i * 2 + 3);         /* :431-434 */
+    for (int i = 0; i < N; i++) obs[e->positions[2 * i] * W + e->positions[2 * i + 1]] = (uint8_t)(i * 2 + 2); /* :436-439 */
+    for (int k = 0; k < H * W; k++) out[k] = (float)obs[k];
+    float *m = out + H * W;
+    for (int i = 0; i < N; i++) { /* get_action_mask SA-env:474-493: "== 0 or odd" (an obstacle, 1, is odd) */
+        int x = e->positions[2 * i], y = e->positions[2 * i + 1];
+        m[i * 5 + 0] = 1.0f;
+        m[i * 5 + 1] = (x > 0 && (obs[(x - 1) * W + y] == 0 || obs[(x - 1) * W + y] % 2 == 1)) ? 1.0f : 0.0f;
+        m[i * 5 + 2] = (y < W - 1 && (obs[x * W + y + 1] == 0 || obs[x * W + y + 1] % 2 == 1)) ? 1.0f : 0.0f;
+        m[i * 5 + 3] = (x < H - 1 && (obs[(x + 1) * W + y] == 0 || obs[(x + 1) * W + y] % 2 == 1)) ? 1.0f : 0.0f;
+        m[i * 5 + 4] = (y > 0 && (obs[x * W + y - 1] == 0 || obs[x * W + y - 1] % 2 == 1)) ? 1.0f : 0.0f;
+    }
+    free(obs);
+}
+
+void moc_reset(moc_env *e, float *obs) { /* SA-env:222-244 */
+    e->step_count = 0;
+    e->episode_blocking_count = 0.0;
+    memset(e->reached_once, 0, e->N);
+    if (e->deterministic) memcpy(e->positions, e->starts, sizeof(int32_t) * 2 * e->N);
+    else moc_generate_starts_goals(e);
+    if (obs) moc_observe(e, obs);
+}
+
+/* SA-env:246-363.  info = {blocking_count_step, goals_reached_step, goals_reached_total, blocking_count_total} */
+int moc_step(moc_env *e, const int32_t *action, float *obs, double *reward_out, uint8_t *done, float *info) {
+    const int N = e->N, H = e->H, W = e->W;
+    e->step_count += 1;
+    double reward = 0;
+    int32_t *prev = (int32_t *)malloc(sizeof(int32_t) * 2 * N), *intended = (int32_t *)malloc(sizeof(int32_t) * 2 * N);
+    uint8_t *reached_goal = (uint8_t *)calloc(N, 1);
+    memcpy(prev, e->positions, sizeof(int32_t) * 2 * N);
+    double blocking_count_step = 0.0, goals_reached_step = 0.0;
+    for (int i = 0; i < N; i++) {
+        int a = action[i];
+        if (a < 0 || a > 4) { /* get_next_position raises ValueError("Invalid action") SA-env:401-403 */
+            free(prev); free(intended); free(reached_goal);
+            return MO_ERR_BAD_ACTION;
+        }
+        int nr = e->positions[2 * i] + ACTION_DELTAS[a][0], nc = e->positions[2 * i + 1] + ACTION_DELTAS[a][1];
+        intended[2 * i] = nr;
+        intended[2 * i + 1] = nc;
+        int ok = nr >= 0 && nr < H && nc >= 0 && nc < W && e->grid[nr * W + nc] == 0;
+        for (int j = 0; ok && j < N; j++)
+            if (j != i && e->positions[2 * j] == nr && e->positions[2 * j + 1] == nc) ok = 0; /* :270-272 */
+        if (ok) {
+            e->positions[2 * i] = nr;
+            e->positions[2 * i + 1] = nc;
+        }
+        if (e->positions[2 * i] == e->goals[2 * i] && e->positions[2 * i + 1] == e->goals[2 * i + 1]) { /* :281-286 */
+            reached_goal[i] = 1;
+            if (!e->reached_once[i]) {
+                e->reached_once[i] = 1;
+                reward += 0.5;
+                goals_reached_step += 1.0;
+            }
+        }
+    }
+    if (obs) moc_observe(e, obs); /* :288-293, after ALL moves */
+    for (int i = 0; i < N; i++) /* :296-300 */
+        for (int j = i + 1; j < N; j++)
+            if (e->positions[2 * i] == e->positions[2 * j] && e->positions[2 * i + 1] == e->positions[2 * j + 1]) reward -= 1;
+    for (int b = 0; b < N; b++) { /* intent-based blocking penalty :303-317 */
+        if (!e->reached_once[b]) continue;
+        if (e->positions[2 * b] != prev[2 * b] || e->positions[2 * b + 1] != prev[2 * b + 1]) continue;
+        for (int o = 0; o < N; o++) {
+            if (o == b || e->reached_once[o]) continue;
+            if (intended[2 * o] == e->positions[2 * b] && intended[2 * o + 1] == e->positions[2 * b + 1]) {
+                reward += e->blocking_penalty;
+                blocking_count_step += 1.0;
+                break;
+            }
+        }
+    }
+    e->episode_blocking_count += blocking_count_step;
+    for (int i = 0; i < N; i++) { /* moving after having reached the goal :320-325 */
+        if (!e->reached_once[i]) continue;
+        if (e->positions[2 * i] != prev[2 * i] || e->positions[2 * i + 1] != prev[2 * i + 1])
+            reward += e->move_after_goal_penalty;
+    }
+    int all = 1;
+    for (int i = 0; i < N; i++) all &= reached_goal[i];
+    int term = 0, trunc = 0;
+    if (all) { /* :328-331 */
+        reward += N;
+        term = 1;
+    } else if (e->step_count >= e->steps_per_episode) { /* :340-348 */
+        for (int i = 0; i < N; i++)
+            if (!reached_goal[i]) reward -= 1;
+        term = 1;
+        trunc = 1;
+    }
+    double total = 0;
+    for (int i = 0; i < N; i++) total += e->reached_once[i];
+    if (info) {
+        info[0] = (float)blocking_count_step;
+        info[1] = (float)goals_reached_step;
+        info[2] = (float)total;
+        info[3] = (float)e->episode_blocking_count;
+    }
+    if (done) { done[0] = (uint8_t)term; done[1] = (uint8_t)trunc; }
+    if (reward_out) *reward_out = reward;
+    free(prev); free(intended); free(reached_goal);
+    return MO_OK;
+}
+
+void moc_view(moc_env *e, int32_t **positions, int32_t **goals, int32_t **starts, uint8_t **reached_once,
+              int32_t **step_count, double **blocking_count) {
+    *positions = e->positions; *goals = e->goals; *starts = e->starts; *reached_once = e->reached_once;
+    *step_count = &e->step_count; *blocking_count = &e->episode_blocking_count;
 }

@@ -143,6 +143,22 @@ int mo_batch_reset(mo_batch *b, float *obs);
 uint64_t mo_rng_bounded(mo_env *e, uint64_t rng_inclusive);
 void mo_rng_choice_noreplace(mo_env *e, int64_t pop, int64_t size, int64_t *out);
 
+/* ---- single-agent (CTE) sibling env: reference src/environments/reference_model_single_agent.py ---- */
+typedef struct moc_env moc_env;
+moc_env *moc_create(int H, int W, int N, int steps_per_episode, int deterministic, double blocking_penalty,
+                    double move_after_goal_penalty, const uint8_t *grid);
+void moc_destroy(moc_env *e);
+int moc_obs_len(const moc_env *e);
+void moc_set_rng(moc_env *e, uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo, int32_t has_uint32,
+                 uint32_t uinteger);
+void moc_get_rng(const moc_env *e, uint64_t out[6]);
+void moc_set_fixed_starts_goals(moc_env *e, const int32_t *starts, const int32_t *goals);
+void moc_generate_starts_goals(moc_env *e);
+void moc_reset(moc_env *e, float *obs);
+int moc_step(moc_env *e, const int32_t *action, float *obs, double *reward, uint8_t *done, float *info);
+void moc_view(moc_env *e, int32_t **positions, int32_t **goals, int32_t **starts, uint8_t **reached_once,
+              int32_t **step_count, double **blocking_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,21 @@ def lib():
     L.mo_rng_bounded.restype = u64
     L.mo_rng_bounded.argtypes = [vp, u64]
     L.mo_rng_choice_noreplace.argtypes = [vp, C.c_int64, C.c_int64, vp]
+    L.moc_create.restype = vp
+    L.moc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp]
+    L.moc_destroy.argtypes = [vp]
+    L.moc_obs_len.restype = C.c_int
+    L.moc_obs_len.argtypes = [vp]
+    L.moc_set_rng.argtypes = [vp, u64, u64, u64, u64, i32, u32]
+    L.moc_get_rng.argtypes = [vp, vp]
+    L.moc_set_fixed_starts_goals.argtypes = [vp, vp, vp]
+    L.moc_generate_starts_goals.argtypes = [vp]
+    L.moc_reset.argtypes = [vp, vp]
+    L.moc_step.restype = C.c_int
+    L.moc_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.moc_view.argtypes = [vp] + [C.POINTER(C.POINTER(C.c_int32))] * 3 + [C.POINTER(C.POINTER(C.c_uint8)),
+                                                                       C.POINTER(C.POINTER(C.c_int32)),
+                                                                       C.POINTER(C.POINTER(C.c_double))]
     _lib = L
     return L
 
@@ -476,3 +491,73 @@ class OracleBatch:
             "step_count": np.array([e.step_count for e in es], dtype=np.int32),
             "rng": np.stack([e.rng_words() for e in es]),
         }
+
+
+class OracleCteEnv:
+    """CPU restatement of the single-agent (CTE) sibling env (reference reference_model_single_agent.py).
+    Mirrors the reference ctor: seeds PCG64 and, unless deterministic, draws generate_starts_goals once."""
+
+    INFO_KEYS = ("blocking_count_step", "goals_reached_step", "goals_reached_total", "blocking_count_total")
+
+    def __init__(self, grid, env_config: dict, *, fixed_starts=None, fixed_goals=None, rng_words=None):
+        grid = np.ascontiguousarray(grid, dtype=np.uint8)
+        self.grid = grid
+        self.H, self.W = grid.shape
+        self.N = int(env_config.get("num_agents", 2))
+        self.deterministic = bool(env_config.get("deterministic", False))
+        self._h = lib().moc_create(self.H, self.W, self.N, int(env_config.get("steps_per_episode", 100)),
+                                   int(self.deterministic), float(env_config.get("blocking_penalty", -0.2)),
+                                   float(env_config.get("move_after_goal_penalty", -0.05)), _ptr(grid))
+        if not self._h:
+            raise ValueError("oracle: bad CTE config")
+        self.L = lib().moc_obs_len(self._h)
+        ptrs = [C.POINTER(C.c_int32)() for _ in range(3)] + [C.POINTER(C.c_uint8)(), C.POINTER(C.c_int32)(),
+                                                              C.POINTER(C.c_double)()]
+        lib().moc_view(self._h, *[C.byref(p) for p in ptrs])
+        self._pos, self._goals, self._starts, self._reached, self._step, self._blk = ptrs
+        w = rng_words if rng_words is not None else pcg64_words(env_config.get("seed", None))
+        w = [int(x) for x in w]
+        lib().moc_set_rng(self._h, w[0], w[1], w[2], w[3], w[4], w[5])
+        if self.deterministic:
+            s = np.ascontiguousarray(fixed_starts, dtype=np.int32)
+            g = np.ascontiguousarray(fixed_goals, dtype=np.int32)
+            lib().moc_set_fixed_starts_goals(self._h, _ptr(s), _ptr(g))
+        else:
+            lib().moc_generate_starts_goals(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().moc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _arr(self, ptr, n, dtype):
+        ct = np.ctypeslib.as_ctypes_type(np.dtype(dtype))
+        return np.frombuffer(C.cast(ptr, C.POINTER(ct * n)).contents, dtype=dtype)
+
+    positions = property(lambda self: self._arr(self._pos, 2 * self.N, np.int32).reshape(self.N, 2))
+    goals = property(lambda self: self._arr(self._goals, 2 * self.N, np.int32).reshape(self.N, 2))
+    starts = property(lambda self: self._arr(self._starts, 2 * self.N, np.int32).reshape(self.N, 2))
+    reached_once = property(lambda self: self._arr(self._reached, self.N, np.uint8))
+    step_count = property(lambda self: int(self._step[0]))
+
+    def rng_words(self):
+        out = np.zeros(6, dtype=np.uint64)
+        lib().moc_get_rng(self._h, _ptr(out))
+        return out
+
+    def reset(self):
+        obs = np.zeros(self.L, dtype=np.float32)
+        lib().moc_reset(self._h, _ptr(obs))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.int32)
+        obs = np.zeros(self.L, dtype=np.float32)
+        rew = C.c_double(0.0)
+        done = np.zeros(2, dtype=np.uint8)
+        info = np.zeros(4, dtype=np.float32)
+        rc = lib().moc_step(self._h, _ptr(a), _ptr(obs), C.byref(rew), _ptr(done), _ptr(info))
+        return rc, obs, float(rew.value), bool(done[0]), bool(done[1]), info

@@ -88,6 +88,22 @@ class _MultiBinary(_Space):
         return x.shape == self.shape and bool(np.all((x == 0) | (x == 1)))
 
 
+class _MultiDiscrete(_Space):
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.shape = self.nvec.shape
+        self.dtype = np.dtype(np.int64)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all((x >= 0) & (x < self.nvec)))
+
+
+class _GymEnv:  # gym.Env: only used as a base class (reference_model_single_agent.py:51,82)
+    def __init__(self, *a, **k):
+        pass
+
+
 def _install_stand_ins() -> None:
     if "gymnasium" not in sys.modules:
         gym = types.ModuleType("gymnasium")
@@ -96,8 +112,9 @@ def _install_stand_ins() -> None:
         spaces.Discrete = _Discrete
         spaces.MultiBinary = _MultiBinary
         spaces.Space = _Space
+        spaces.MultiDiscrete = _MultiDiscrete
         gym.spaces = spaces
-        gym.Env = object
+        gym.Env = _GymEnv
         sys.modules["gymnasium"] = gym
         sys.modules["gymnasium.spaces"] = spaces
     if "ray" not in sys.modules:
@@ -164,6 +181,19 @@ class injected_grid:
         _, gg = load_reference()
         gg.get_grid = self._saved
         return False
+
+
+def make_reference_single_agent_env(env_config: dict, grid: np.ndarray | None = None):
+    """The reference's single-agent (CTE) env, optionally on an injected synthetic grid."""
+    load_reference()
+    from src.environments.reference_model_single_agent import ReferenceModel as SingleRef  # type: ignore
+
+    if grid is None:
+        return SingleRef(dict(env_config))
+    cfg = dict(env_config)
+    cfg.setdefault("env_name", "synthetic")
+    with injected_grid(grid):
+        return SingleRef(cfg)
 
 
 def make_reference_env(env_config: dict, grid: np.ndarray | None = None):
