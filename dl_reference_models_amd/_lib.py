@@ -26,6 +26,7 @@ FLAG_BLOCKING_PRESSURE = 8
 FLAG_LIFELONG = 16
 FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
+FLAG_SINGLE_AGENT = 256
 FLAG_GENERIC_KERNEL = 0x80000000
 
 INFO_ALL = 14
@@ -44,7 +45,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_many", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
+    "mapf_step", "mapf_step_many", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
 )
 
 
@@ -127,6 +128,12 @@ def load():
     L.mapf_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mapf_step_many.restype = C.c_int
     L.mapf_step_many.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.mapf_cte_configure.restype = C.c_int
+    L.mapf_cte_configure.argtypes = [vp, C.c_double, C.c_double]
+    L.mapf_cte_reset.restype = C.c_int
+    L.mapf_cte_reset.argtypes = [vp, vp, vp, vp]
+    L.mapf_cte_step.restype = C.c_int
+    L.mapf_cte_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mapf_observe.restype = C.c_int
     L.mapf_observe.argtypes = [vp, vp, vp]
     L.mapf_get_episode_stats.restype = C.c_int

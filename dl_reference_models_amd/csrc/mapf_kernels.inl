@@ -677,10 +677,20 @@ __device__ __forceinline__ void flush_obs_full(const Params &p, const Io &io, fl
 }
 
 template <class K, int LPE>
+__device__ __forceinline__ void flush_rows(const Io &io, const float *stage, int lane, int env0, int ngroups, int sel,
+                                           const int NL);
+
+template <class K, int LPE>
 __device__ __forceinline__ void flush_obs(const Params &p, const Io &io, const float *stage, int lane, int env0,
                                           int ngroups, int sel) {
+    flush_rows<K, LPE>(io, stage, lane, env0, ngroups, sel, K::N(p) * K::L(p));
+}
+
+// NL = floats per env
+template <class K, int LPE>
+__device__ __forceinline__ void flush_rows(const Io &io, const float *stage, int lane, int env0, int ngroups, int sel,
+                                           const int NL) {
     constexpr int G = 64 / LPE;
-    const int NL = K::N(p) * K::L(p);
     const uint64_t valid = __ballot((lane / LPE) < ngroups);
     const uint64_t m0 = __ballot((lane / LPE) < ngroups && sel == 0);
     const uint64_t m1 = __ballot((lane / LPE) < ngroups && sel == 1);
@@ -1317,6 +1327,291 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
     }
     if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);
+}
+
+// ================================================================================================
+// Single-agent (CTE) sibling env: /root/reference/src/environments/reference_model_single_agent.py ("SA-env").
+// One policy drives all agents: same sequential move rule, but a FULL-GRID observation (codes 0 free,
+// 1 obstacle, 2+2i agent i, 3+2i goal i; agents drawn over goals, SA-env:407-441), a joint 5N action mask
+// (incl. the reference's quirk that an obstacle, being odd, counts as enterable, SA-env:483-493), a scalar
+// float64 reward (SA-env:246-363) and rejection-sampled starts/goals (SA-env:158-191).
+// LDS staging holds one row of H*W + 5N floats per env.
+// ================================================================================================
+struct CteIo {
+    AgentRec *agents;
+    int *scal;
+    const uint64_t *grid_rows;
+    int B, H, W, steps_per_episode;
+    int lds_tab_off, lds_stage_off, lds_scratch_off;
+    double blocking_penalty, move_after_goal_penalty;
+    const int8_t *actions;
+    float *obs;
+    double *reward;
+    uint8_t *terminated, *truncated;
+    float *info;  // [B][4] blocking_count_step, goals_reached_step, goals_reached_total, blocking_count_total
+    float *final_obs;
+    const uint8_t *env_mask;
+    int auto_reset;
+};
+
+// full-grid observation + joint mask of the groups' current state -> staging rows
+template <int LPE>
+__device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const uint64_t *lrows, float *srow,
+                                            bool env_ok, bool is_agent, int a, uint32_t pos, uint32_t goal) {
+    const int H = io.H, W = io.W, HW = H * W;
+    if (env_ok) {
+        for (int r = 0; r < H; r++) {
+            const uint64_t bits = lrows[r];
+            for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
+        }
+    }
+    wave_lds_sync();
+    if (is_agent) srow[(goal >> 8) * W + (goal & 255u)] = (float)(2 * a + 3);  // goals first ...
+    wave_lds_sync();
+    if (is_agent) srow[(pos >> 8) * W + (pos & 255u)] = (float)(2 * a + 2);   // ... agents overwrite goals
+    wave_lds_sync();
+    if (is_agent) {
+        const int x = (int)(pos >> 8), y = (int)(pos & 255u);
+        float *m = srow + HW + 5 * a;
+        auto open = [&](int r, int c) {  // "== 0 or odd" on the cell code (SA-env:483)
+            const int v = (int)srow[r * W + c];
+            return (v == 0 || (v & 1)) ? 1.0f : 0.0f;
+        };
+        m[0] = 1.0f;
+        m[1] = x > 0 ? open(x - 1, y) : 0.0f;
+        m[2] = y < W - 1 ? open(x, y + 1) : 0.0f;
+        m[3] = x < H - 1 ? open(x + 1, y) : 0.0f;
+        m[4] = y > 0 ? open(x, y - 1) : 0.0f;
+    }
+    wave_lds_sync();
+}
+
+// SA-env:158-191 for the groups with do_reset: one rng.choice(F) (= bounded(F-1)) per attempt, rejection until unique
+template <int LPE>
+__device__ __forceinline__ void cte_sample_starts_goals(const Params &p, const int N, int16_t *scratch, int grp, int a,
+                                                        int env, bool do_reset, bool is_agent, Lane &st) {
+    uint16_t *starts = reinterpret_cast<uint16_t *>(scratch + grp * p.scratch_i16);
+    uint16_t *goals = starts + N;
+    if (do_reset && a == 0) {
+        Pcg g;
+        pcg_load(g, p.rng + (size_t)env * 6);
+        const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+        const uint32_t top = (uint32_t)(p.n_free[env] - 1);
+        bool gave_up = false;
+        for (int i = 0; i < N && !gave_up; i++) {
+            int guard = 0;
+            for (;; guard++) {
+                const uint16_t cell = fc[pcg_bounded(g, top)];
+                bool clash = false;
+                for (int j = 0; j < i; j++) clash |= starts[j] == cell;
+                if (!clash) { starts[i] = cell; break; }
+                if (guard > (1 << 20)) { gave_up = true; break; }  // F >= 2N is checked at set_grids; guard only
+            }
+        }
+        for (int i = 0; i < N && !gave_up; i++) {
+            int guard = 0;
+            for (;; guard++) {
+                const uint16_t cell = fc[pcg_bounded(g, top)];
+                bool clash = false;
+                for (int j = 0; j < i; j++) clash |= goals[j] == cell;
+                for (int j = 0; j < N; j++) clash |= starts[j] == cell;
+                if (!clash) { goals[i] = cell; break; }
+                if (guard > (1 << 20)) { gave_up = true; break; }
+            }
+        }
+        if (gave_up) raise_error(p, MAPF_ERR_FEW_FREE, env, 0, 0);
+        pcg_store(g, p.rng + (size_t)env * 6);
+    }
+    wave_lds_sync();
+    if (do_reset && is_agent) {
+        st.start = starts[a];
+        st.goal = goals[a];
+    }
+    wave_lds_sync();
+}
+
+template <int LPE>
+__global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp, const CteIo io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t *lrows = reinterpret_cast<uint64_t *>(lds_raw);
+    float *stage = reinterpret_cast<float *>(lds_raw + io.lds_stage_off);
+    int16_t *scratch = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch_off);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G, ngroups = min(G, io.B - env0), N = p.N;
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    const bool is_agent = env_ok && a < N;
+    const int row_len = io.H * io.W + 5 * N;
+    load_rows_to_lds(io.grid_rows, io.H, lrows, lane, env0, ngroups);
+    Lane st;
+    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
+    wave_lds_sync();
+    if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
+    if (do_reset) {  // SA-env:222-232
+        st.pos = st.start;
+        st.flags = 0;
+    }
+    if (io.obs) {
+        cte_observe<LPE>(io, N, lrows + grp * io.H, stage + (size_t)grp * row_len, env_ok, is_agent, a, st.pos, st.goal);
+        Io fio;
+        fio.obs = io.obs;
+        fio.final_obs = nullptr;
+        flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
+    }
+    if (do_reset) {
+        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (a == 0) {
+            int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
+            sp[0] = make_int4(0, 0, 0, 0);  // step_count, -, _episode_blocking_count, -
+        }
+    }
+}
+
+template <int LPE>
+__global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, const CteIo io) {
+    const Params &p = *pp;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint64_t *lrows = reinterpret_cast<uint64_t *>(lds_raw);
+    uint4 *tab = reinterpret_cast<uint4 *>(lds_raw + io.lds_tab_off);
+    float *stage = reinterpret_cast<float *>(lds_raw + io.lds_stage_off);
+    int16_t *scratch = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch_off);
+    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int env0 = blockIdx.x * G, ngroups = min(G, io.B - env0), N = p.N, H = io.H, W = io.W;
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    const bool is_agent = env_ok && a < N;
+    const int row_len = H * W + 5 * N;
+    uint4 *tabg = tab + grp * LPE;
+    const uint64_t *myrows = lrows + grp * H;
+    float *srow = stage + (size_t)grp * row_len;
+
+    load_rows_to_lds(io.grid_rows, H, lrows, lane, env0, ngroups);
+    Lane st;
+    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
+    int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
+    wave_lds_sync();
+
+    // invalid action: get_next_position raises mid-loop (SA-env:262, :401-403); agents before it were processed
+    const bool bad = is_agent && (act < 0 || act > 4);
+    const uint64_t badm = gballot<LPE>(bad, lane);
+    const bool errored = badm != 0;
+    const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+    const bool live = is_agent && a < n_live;
+    if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
+    if (!live) act = 0;
+    int step_count = sc0.x + 1;  // SA-env:247
+
+    // move (SA-env:259-274): the same sequential rule as the multi-agent env
+    const uint32_t old = st.pos;
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0), dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
+    const bool inb = tr >= 0 && tr < H && tc >= 0 && tc < W;
+    const uint64_t trow = (live && inb) ? myrows[tr] : ~0ull;
+    const bool want = live && act != 0 && inb && !((trow >> tc) & 1ull);
+    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
+    uint32_t cur = old;
+    if (__any(want)) cur = resolve_moves<KRuntime, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
+    const bool moved = cur != old;
+
+    // goal bookkeeping (SA-env:281-286)
+    bool reached_once = (st.flags & kFlagReached) != 0;
+    const bool on_goal = live && cur == st.goal;
+    const bool first = on_goal && !reached_once;
+    reached_once = reached_once || first;
+    const int k_first = __popcll(gballot<LPE>(first, lane));
+
+    // all-pairs pass: intent blocking (SA-env:303-316) and coincidences (SA-env:296-300)
+    {
+        uint4 ent;
+        ent.x = old | (cur << 16);
+        ent.y = 0;
+        ent.z = (is_agent && !reached_once) ? intended1 : 0xFFFFFFFFu;
+        ent.w = 0u;
+        tabg[a] = ent;
+    }
+    wave_lds_sync();
+    bool blocks = false;
+    int same = 0;
+    const uint32_t mycell1 = cur + 0x0101u;
+    for (int j = 0; j < N; j++) {
+        const uint4 e = tabg[j];
+        blocks |= e.z == mycell1;
+        same += ((e.x >> 16) == cur) ? 1 : 0;
+    }
+    wave_lds_sync();
+    const bool blocking = is_agent && reached_once && !moved && blocks;
+    const int m_block = __popcll(gballot<LPE>(blocking, lane));
+    const int q_move = __popcll(gballot<LPE>(is_agent && reached_once && moved, lane));  // SA-env:320-325
+    int coll2 = is_agent ? same - 1 : 0;  // each coinciding pair is seen from both sides
+    for (int o = LPE / 2; o > 0; o >>= 1) coll2 += __shfl_xor(coll2, o, LPE);
+    const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+
+    // reward in float64, in the reference's order of additions (SA-env:253-346)
+    double reward = 0.5 * (double)k_first - (double)(coll2 / 2);
+    for (int i = 0; i < N; i++) if (i < m_block) reward += io.blocking_penalty;
+    for (int i = 0; i < N; i++) if (i < q_move) reward += io.move_after_goal_penalty;
+    int term = 0, trunc = 0;
+    if (n_on_goal == N) {
+        reward += (double)N;
+        term = 1;
+    } else if (step_count >= io.steps_per_episode) {
+        for (int i = 0; i < N; i++) if (i < N - n_on_goal) reward -= 1.0;
+        term = 1;
+        trunc = 1;
+    }
+    const int blocking_total = sc0.z + m_block;
+    const int reached_total = __popcll(gballot<LPE>(is_agent && reached_once, lane));
+    const bool done = env_ok && !errored && (term | trunc);
+    const bool do_reset = done && io.auto_reset;
+
+    // observation after ALL moves (SA-env:288-293)
+    st.pos = cur;
+    st.flags = reached_once ? kFlagReached : 0;
+    Io fio;
+    fio.obs = io.obs;
+    fio.final_obs = io.final_obs;
+    if (io.obs || io.final_obs) {
+        cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, cur, st.goal);
+        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
+        flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, sel, row_len);
+    }
+    if (env_ok && !errored && a == 0) {
+        if (io.reward) io.reward[env] = reward;
+        if (io.terminated) io.terminated[env] = (uint8_t)term;
+        if (io.truncated) io.truncated[env] = (uint8_t)trunc;
+        if (io.info) {
+            float4 v = make_float4((float)m_block, (float)k_first, (float)reached_total, (float)blocking_total);
+            *reinterpret_cast<float4 *>(io.info + (size_t)env * 4) = v;
+        }
+    }
+    int blocking_keep = errored ? sc0.z : blocking_total;  // the exception fires before the penalties are booked
+
+    if (__any(do_reset)) {
+        wave_lds_sync();
+        if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
+            cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
+        if (do_reset) {
+            st.pos = st.start;
+            st.flags = 0;
+            step_count = 0;
+            blocking_keep = 0;
+        }
+        if (io.obs) {
+            cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, st.pos, st.goal);
+            flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
+        }
+    }
+    if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (env_ok && a == 0) {
+        int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
+        sp[0] = make_int4(step_count, 0, blocking_keep, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

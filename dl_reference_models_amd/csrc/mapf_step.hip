@@ -54,6 +54,8 @@ struct mapf_engine {
     int lpe = 0;
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
+    bool cte = false;  // single-agent (CTE) variant
+    double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
     int blocks = 0;
     int lds_bytes = 0;
     bool grids_set = false;
@@ -192,6 +194,7 @@ extern "C" {
 uint32_t mapf_version(void) { return (MAPF_VERSION_MAJOR << 16) | MAPF_VERSION_MINOR; }
 
 int32_t mapf_obs_len(const mapf_config *cfg) {
+    if (cfg->flags & MAPF_FLAG_SINGLE_AGENT) return cfg->height * cfg->width + 5 * cfg->num_agents;  // SA-env:124-141
     const int V = 2 * cfg->sensor_range + 1;
     int L = V * V + 2;
     if (cfg->flags & MAPF_FLAG_GOAL_DISTANCE) L += 1;
@@ -227,8 +230,14 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (!(lpe == 4 || lpe == 8 || lpe == 16 || lpe == 32 || lpe == 64) || lpe < c.num_agents)
         return fail(nullptr, MAPF_ERR_CONFIG, "lanes_per_env must be a power of two in [4,64] and >= num_agents");
 
+    const bool cte = (c.flags & MAPF_FLAG_SINGLE_AGENT) != 0;
+    if (cte && !c.lanes_per_env) {
+        // one staging row of H*W + 5N floats per env: widen the groups until a wave's rows fit 64 KiB of LDS
+        while (lpe < 64 && (64 / lpe) * (c.height * c.width + 5 * c.num_agents) * 4 > 56 * 1024) lpe <<= 1;
+    }
     mapf_engine *e = new mapf_engine();
     e->cfg = c;
+    e->cte = cte;
     e->lpe = lpe;
     {
         const int vv = (2 * c.sensor_range + 1) * (2 * c.sensor_range + 1);
@@ -246,7 +255,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
     p.flags = c.flags & ~MAPF_FLAG_GENERIC_KERNEL;
-    e->special = match_specialization(c, lpe, c.lock_nearby_manhattan);
+    e->special = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
     p.nearby = c.lock_nearby_manhattan;
@@ -271,7 +280,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * H * 8) + 15) & ~15;
     const int tab_bytes = 64 * 16;  // one 16-byte entry per lane
-    const int stage_bytes = ((G * N * p.L * 4) + 15) & ~15;
+    const int stage_bytes = ((G * (cte ? (H * W + 5 * N) : N * p.L) * 4) + 15) & ~15;
     const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
     p.lds_tab_off = rows_bytes;
     p.lds_stage_off = rows_bytes + tab_bytes;
@@ -534,6 +543,7 @@ int mapf_set_fixed_starts_goals(mapf_handle e, const int16_t *starts, const int1
 int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream) {
     if (!e) return MAPF_ERR_CONFIG;
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_reset");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "handle was created with MAPF_FLAG_SINGLE_AGENT: use mapf_cte_reset");
     Io io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;
@@ -561,6 +571,7 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
               float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream) {
     if (!e || !actions) return fail(e, MAPF_ERR_CONFIG, "null argument");
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "handle was created with MAPF_FLAG_SINGLE_AGENT: use mapf_cte_step");
     Io io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;
@@ -596,6 +607,7 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     if (!e || !actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
     if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step_many");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_step_many is not available for the single-agent variant");
     Io io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;
@@ -625,9 +637,82 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     return MAPF_OK;
 }
 
+static CteIo make_cte_io(const mapf_engine *e) {
+    CteIo io;
+    memset(&io, 0, sizeof io);
+    io.agents = e->d_agents;
+    io.scal = e->d_scal;
+    io.grid_rows = e->d_rows;
+    io.B = e->p.B;
+    io.H = e->p.H;
+    io.W = e->p.W;
+    io.steps_per_episode = e->p.steps_per_episode;
+    io.lds_tab_off = e->p.lds_tab_off;
+    io.lds_stage_off = e->p.lds_stage_off;
+    io.lds_scratch_off = e->p.lds_scratch_off;
+    io.blocking_penalty = e->cte_blocking_penalty;
+    io.move_after_goal_penalty = e->cte_move_after_goal_penalty;
+    return io;
+}
+
+static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s) {
+#define MAPF_CASE(L)                                                                                                 \
+    case L:                                                                                                          \
+        if (step) hipLaunchKernelGGL((k_cte_step<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);   \
+        else hipLaunchKernelGGL((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);      \
+        return hipGetLastError();
+    switch (e->lpe) {
+        MAPF_CASE(4)
+        MAPF_CASE(8)
+        MAPF_CASE(16)
+        MAPF_CASE(32)
+        MAPF_CASE(64)
+    }
+#undef MAPF_CASE
+    return hipErrorInvalidValue;
+}
+
+int mapf_cte_configure(mapf_handle e, double blocking_penalty, double move_after_goal_penalty) {
+    if (!e || !e->cte) return fail(e, MAPF_ERR_STATE, "not a MAPF_FLAG_SINGLE_AGENT handle");
+    e->cte_blocking_penalty = blocking_penalty;
+    e->cte_move_after_goal_penalty = move_after_goal_penalty;
+    return MAPF_OK;
+}
+
+int mapf_cte_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream) {
+    if (!e || !e->cte) return fail(e, MAPF_ERR_STATE, "not a MAPF_FLAG_SINGLE_AGENT handle");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_cte_reset");
+    CteIo io = make_cte_io(e);
+    io.env_mask = env_mask;
+    io.obs = obs;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, launch_cte(e, io, false, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+int mapf_cte_step(mapf_handle e, const int8_t *actions, float *obs, double *reward, uint8_t *terminated,
+                  uint8_t *truncated, float *info, float *final_obs, int32_t auto_reset, void *stream) {
+    if (!e || !e->cte) return fail(e, MAPF_ERR_STATE, "not a MAPF_FLAG_SINGLE_AGENT handle");
+    if (!actions) return fail(e, MAPF_ERR_CONFIG, "null argument");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_cte_step");
+    CteIo io = make_cte_io(e);
+    io.actions = actions;
+    io.obs = obs;
+    io.reward = reward;
+    io.terminated = terminated;
+    io.truncated = truncated;
+    io.info = info;
+    io.final_obs = final_obs;
+    io.auto_reset = auto_reset;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
 int mapf_observe(mapf_handle e, float *obs, void *stream) {
     if (!e || !obs) return fail(e, MAPF_ERR_CONFIG, "null argument");
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_observe");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_observe is not available for the single-agent variant");
     Io io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;

@@ -16,6 +16,8 @@ try:  # pragma: no cover - not installed in the build image
     Box = _gym.spaces.Box
     Discrete = _gym.spaces.Discrete
     MultiBinary = _gym.spaces.MultiBinary
+    MultiDiscrete = _gym.spaces.MultiDiscrete
+    GymEnv = _gym.Env
     HAVE_GYMNASIUM = True
 except ImportError:
     HAVE_GYMNASIUM = False
@@ -79,6 +81,24 @@ except ImportError:
 
         def sample(self):
             return self._generator().integers(0, 2, size=self.shape).astype(self.dtype)
+
+
+    class MultiDiscrete(_Space):
+        def __init__(self, nvec):
+            self.nvec = np.asarray(nvec, dtype=np.int64)
+            self.shape = self.nvec.shape
+            self.dtype = np.dtype(np.int64)
+
+        def contains(self, x) -> bool:
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all((x >= 0) & (x < self.nvec)))
+
+        def sample(self):
+            return self._generator().integers(0, self.nvec).astype(self.dtype)
+
+    class GymEnv:  # gym.Env stand-in: a plain base class
+        def __init__(self, *a, **k):
+            pass
 
 
 try:  # pragma: no cover - not installed in the build image

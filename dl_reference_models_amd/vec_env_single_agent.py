@@ -1,0 +1,144 @@
+"""Batched tensor API of the single-agent (CTE) sibling env: B independent copies of the reference's
+``src/environments/reference_model_single_agent.py::ReferenceModel`` ("SA-env") on one GPU.
+
+Same construction keys as the reference (``steps_per_episode``, ``num_agents``, ``deterministic``,
+``blocking_penalty`` -0.2, ``move_after_goal_penalty`` -0.05, ``seed``, ``env_name``; SA-env:84-114) plus the
+extension keys of ``VecReferenceModel`` (``num_envs``, ``device``, ``grid``, ``seeds``, ``rng_words``,
+``fixed_starts`` / ``fixed_goals``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import get_grid as grid_tables
+from .vec_env import pcg64_words
+
+INFO_KEYS = ("blocking_count_step", "goals_reached_step", "goals_reached_total", "blocking_count_total")
+
+
+class VecSingleAgentReferenceModel:
+    def __init__(self, env_config: dict):
+        cfg = dict(env_config)
+        self._lib = L.load()
+        self.device = torch.device(cfg.get("device", "cuda:0"))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.num_envs = B = int(cfg.get("num_envs", 1))
+        self.num_agents = N = int(cfg.get("num_agents", 2))
+        self.steps_per_episode = int(cfg.get("steps_per_episode", 100))
+        self.deterministic = bool(cfg.get("deterministic", False))
+        grid = cfg.get("grid", None)
+        if grid is None:
+            grid = grid_tables.get_grid(cfg["env_name"])
+        grid = np.ascontiguousarray(grid, dtype=np.uint8)
+        shared, self.grids = (1, grid[None]) if grid.ndim == 2 else (0, grid)
+        H, W = int(self.grids.shape[1]), int(self.grids.shape[2])
+        self.grid_shape = (H, W)
+        flags = L.FLAG_SINGLE_AGENT | (L.FLAG_DETERMINISTIC if self.deterministic else 0)
+        c = L.MapfConfig(B, H, W, N, 0, self.steps_per_episode, flags, 1, 1, 1, 1, 0.0, int(self.device.index),
+                         int(cfg.get("lanes_per_env", 0)))
+        self.obs_len = int(self._lib.mapf_obs_len(C.byref(c)))
+        h = C.c_void_p()
+        rc = self._lib.mapf_create(C.byref(c), C.byref(h))
+        if rc != L.MAPF_OK:
+            raise ValueError(f"mapf_create failed ({rc}): {self._lib.mapf_last_error(None).decode()}")
+        self._h = h
+        self._check(self._lib.mapf_cte_configure(h, float(cfg.get("blocking_penalty", -0.2)),
+                                                 float(cfg.get("move_after_goal_penalty", -0.05))))
+        self._check(self._lib.mapf_set_grids(h, self.grids.ctypes.data_as(C.c_void_p), shared), ValueError)
+        if cfg.get("rng_words", None) is not None:
+            words = np.ascontiguousarray(cfg["rng_words"], dtype=np.uint64).reshape(B, 6)
+        else:
+            seeds = cfg.get("seeds", None)
+            if seeds is None:
+                seed = cfg.get("seed", None)
+                seeds = [None] * B if seed is None else [int(seed) + b for b in range(B)]
+            words = np.stack([pcg64_words(s) for s in seeds])
+        self._check(self._lib.mapf_set_rng_state(h, words.ctypes.data_as(C.c_void_p)))
+        dev = self.device
+        with torch.cuda.device(dev):
+            self._obs = torch.zeros((B, self.obs_len), dtype=torch.float32, device=dev)
+            self._final_obs = torch.zeros((B, self.obs_len), dtype=torch.float32, device=dev)
+            self._reward = torch.zeros((B,), dtype=torch.float64, device=dev)
+            self._terminated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self._truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
+            self._info = torch.zeros((B, 4), dtype=torch.float32, device=dev)
+        if self.deterministic:  # fixed tables (SA-env:109-112)
+            fs, fg = cfg.get("fixed_starts", None), cfg.get("fixed_goals", None)
+            if fs is None or fg is None:
+                s = grid_tables.get_start_positions(cfg["env_name"], N)
+                g = grid_tables.get_goal_positions(cfg["env_name"], N)
+                fs = np.array([s[f"agent_{i}"] for i in range(N)], dtype=np.int16)
+                fg = np.array([g[f"agent_{i}"] for i in range(N)], dtype=np.int16)
+            fs = np.ascontiguousarray(np.broadcast_to(np.asarray(fs, np.int16).reshape(-1, N, 2), (B, N, 2)))
+            fg = np.ascontiguousarray(np.broadcast_to(np.asarray(fg, np.int16).reshape(-1, N, 2), (B, N, 2)))
+            self._check(self._lib.mapf_set_fixed_starts_goals(
+                h, fs.ctypes.data_as(C.c_void_p), fg.ctypes.data_as(C.c_void_p)), ValueError)
+        else:  # the ctor's own generate_starts_goals() draw (SA-env:113-114)
+            self._check(self._lib.mapf_cte_reset(h, None, None, self._stream()))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc, exc=RuntimeError):
+        if rc != L.MAPF_OK:
+            raise exc(f"{self._lib.mapf_last_error(self._h).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mapf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, env_mask=None) -> torch.Tensor:
+        mptr = None
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = C.c_void_p(env_mask.data_ptr())
+        self._check(self._lib.mapf_cte_reset(self._h, mptr, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        return self._obs
+
+    def step(self, actions: torch.Tensor, auto_reset: bool = True, want_final_obs: bool = False) -> dict:
+        """actions: int8 [B, N] (the reference's MultiDiscrete([5]*N) action per env)."""
+        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        if tuple(actions.shape) != (self.num_envs, self.num_agents):
+            raise ValueError(f"actions must have shape {(self.num_envs, self.num_agents)}")
+        fo = C.c_void_p(self._final_obs.data_ptr()) if (want_final_obs and auto_reset) else None
+        self._check(self._lib.mapf_cte_step(
+            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()), C.c_void_p(self._reward.data_ptr()),
+            C.c_void_p(self._terminated.data_ptr()), C.c_void_p(self._truncated.data_ptr()),
+            C.c_void_p(self._info.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
+        return {"obs": self._obs, "reward": self._reward, "terminated": self._terminated, "truncated": self._truncated,
+                "info": self._info, "final_obs": self._final_obs if fo is not None else None}
+
+    def poll_error(self):
+        env, agent, value = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        rc = self._lib.mapf_poll_error(self._h, self._stream(), C.byref(env), C.byref(agent), C.byref(value))
+        if rc == L.MAPF_OK:
+            return
+        if rc == L.MAPF_ERR_BAD_ACTION:
+            raise ValueError("Invalid action")  # SA-env:401-403
+        raise RuntimeError(self._lib.mapf_last_error(self._h).decode())
+
+    def get_state(self) -> dict:
+        B, N = self.num_envs, self.num_agents
+        out = {"positions": np.zeros((B, N, 2), np.int16), "goals": np.zeros((B, N, 2), np.int16),
+               "starts": np.zeros((B, N, 2), np.int16), "reached": np.zeros((B, N), np.uint8),
+               "counters": np.zeros((B, L.NUM_COUNTERS), np.int32), "rng_words": np.zeros((B, 6), np.uint64)}
+        s = L.MapfState(positions=out["positions"].ctypes.data_as(C.c_void_p), goals=out["goals"].ctypes.data_as(C.c_void_p),
+                        starts=out["starts"].ctypes.data_as(C.c_void_p), reached=out["reached"].ctypes.data_as(C.c_void_p),
+                        counters=out["counters"].ctypes.data_as(C.c_void_p),
+                        rng_words=out["rng_words"].ctypes.data_as(C.c_void_p))
+        self._check(self._lib.mapf_get_state(self._h, C.byref(s)))
+        return out

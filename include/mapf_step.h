@@ -63,6 +63,7 @@ extern "C" {
 #define MAPF_FLAG_LIFELONG 16u            /* lifelong_mapf [off] */
 #define MAPF_FLAG_LOCK_METRICS 32u        /* enable_lock_metrics [on] */
 #define MAPF_FLAG_DETERMINISTIC 64u       /* deterministic [off]: reset() re-places agents on fixed starts, no RNG */
+#define MAPF_FLAG_SINGLE_AGENT 256u        /* the handle runs the single-agent (CTE) sibling env: use the mapf_cte_* calls */
 #define MAPF_FLAG_GENERIC_KERNEL 0x80000000u /* engine knob (tests): never pick a compile-time specialised step kernel */
 
 /* status codes */
@@ -203,6 +204,23 @@ int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, 
  * ended an episode is the reset observation). */
 int mapf_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
                    uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream);
+
+/* ---- single-agent (CTE) sibling env: reference src/environments/reference_model_single_agent.py ("SA-env") ----
+ * One policy drives all N agents (gym.Env, MultiDiscrete([5]*N) action).  Create the handle with
+ * MAPF_FLAG_SINGLE_AGENT (only MAPF_FLAG_DETERMINISTIC is meaningful besides it; sensor_range and the lock
+ * settings are unused), then set grids / RNG / fixed tables as usual.  Flat observation = H*W cell codes
+ * (0 free, 1 obstacle, 2+2i agent i, 3+2i goal i; SA-env:407-441) followed by the joint 5N action mask
+ * (SA-env:443-495); mapf_obs_len() returns H*W + 5N.
+ *   mapf_cte_configure  <- blocking_penalty / move_after_goal_penalty of the ctor   SA-env:92-93 (defaults -0.2, -0.05)
+ *   mapf_cte_reset      <- reset()   SA-env:222-244 (+ generate_starts_goals :158-191); obs NULL = the ctor's draw :113-114
+ *   mapf_cte_step       <- step()    SA-env:246-363:  reward double [B] (the reference's float64 sum, same order of
+ *                          additions), terminated / truncated uint8 [B], info float32 [B][4] =
+ *                          {blocking_count_step, goals_reached_step, goals_reached_total, blocking_count_total};
+ *                          info["action_mask"] is the tail of the observation. */
+int mapf_cte_configure(mapf_handle h, double blocking_penalty, double move_after_goal_penalty);
+int mapf_cte_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *obs /* device */, void *stream);
+int mapf_cte_step(mapf_handle h, const int8_t *actions, float *obs, double *reward, uint8_t *terminated,
+                  uint8_t *truncated, float *info, float *final_obs, int32_t auto_reset, void *stream);
 
 /* observation of every agent from the CURRENT state, nothing is modified: what the reference returns when
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().

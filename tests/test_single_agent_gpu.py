@@ -1,0 +1,74 @@
+"""Single-agent (CTE) sibling env on the GPU: golden traces recorded from the reference, the oracle at size, the
+drop-in gym.Env class, and the reference's own dtype/bounds test for this env."""
+
+import numpy as np
+import pytest
+
+from trace_util import (CTE_FIXTURES, CteEngineStepper, CteOracleStepper, _eq, load_golden, replay_cte_trace, synth_grids)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", CTE_FIXTURES)
+def test_cte_engine_matches_golden_trace(name):
+    fx = load_golden(name)
+    replay_cte_trace(CteEngineStepper, fx)
+
+
+@pytest.mark.parametrize("shape", [(512, 16, 16, 4, {}), (300, 32, 32, 8, {"blocking_penalty": -0.3}),
+                                   (40, 64, 64, 64, {"steps_per_episode": 50}), (70, 5, 9, 7, {"steps_per_episode": 30})])
+def test_cte_engine_vs_oracle(shape):
+    B, H, W, N, extra = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "steps_per_episode": 60}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, 0.2, N, base_seed=140_000)
+    seeds = list(range(B))
+    a, b = CteEngineStepper(grids, cfg, seeds=seeds), CteOracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset obs", a.reset(), b.reset())
+    rng = np.random.default_rng(4)
+    blocking = goals = 0.0
+    for t in range(150):
+        pos, gl = b.positions().astype(int), b.goals().astype(int)
+        d = gl - pos
+        greedy = np.where(np.abs(d[..., 0]) >= np.abs(d[..., 1]), np.where(d[..., 0] > 0, 3, np.where(d[..., 0] < 0, 1, 0)),
+                          np.where(d[..., 1] > 0, 2, 4))
+        acts = np.where(rng.random((B, N)) < 0.6, greedy, rng.integers(0, 5, size=(B, N))).astype(np.int8)
+        ra, rb = a.step(acts), b.step(acts)
+        for k in ("obs", "reward", "terminated", "truncated", "info"):
+            _eq(k, ra[k], rb[k], t)
+        blocking += rb["info"][:, 0].sum()
+        goals += rb["info"][:, 1].sum()
+    _eq("positions", a.positions(), b.positions())
+    _eq("rng", a.rng_words(), b.rng_words())
+    assert goals > 0
+
+
+def test_single_agent_dropin_class_like_the_reference_dtype_test():
+    """reference tests/test_reference_model_observation_dtypes.py:44-56 against the drop-in class."""
+    from dl_reference_models_amd.reference_model_single_agent import ReferenceModel
+
+    env = ReferenceModel({"env_name": "ReferenceModel-2-1", "seed": 123, "deterministic": True, "num_agents": 4,
+                          "steps_per_episode": 20, "sensor_range": 2, "render_env": False,
+                          "validate_observation_space": True})
+    obs, info = env.reset()
+    assert obs.dtype == np.float32 and env.observation_space.contains(obs)
+    mask = obs[env._obs_slices["action_mask"]]
+    assert np.all(np.isin(mask, np.array([0.0, 1.0], dtype=np.float32))) and np.array_equal(mask, info["action_mask"])
+    nxt, reward, term, trunc, inf = env.step([0] * env.num_agents)
+    assert nxt.dtype == np.float32 and env.observation_space.contains(nxt) and isinstance(reward, float)
+    assert set(inf) == {"action_mask", "blocking_count_step", "goals_reached_step", "goals_reached_total",
+                        "blocking_count_total"}
+    split = env.split_flat_observation(nxt)
+    assert split["observations"].shape == env.grid.shape
+    # the deterministic fixture of the reference (gs_cte_named_2_1_det) through the dict-free gym API
+    fx = load_golden("gs_cte_named_2_1_det")
+    env2 = ReferenceModel(dict(fx["config"], seed=123))
+    o, _ = env2.reset()
+    assert np.array_equal(o, fx["reset0_obs"][0])
+    for t in range(40):
+        o, r, te, tr, _i = env2.step(fx["actions"][t, 0].tolist())
+        assert np.array_equal(o, fx["obs"][t, 0]) and r == fx["reward"][t, 0] and te == bool(fx["terminated"][t, 0])
+        if te or tr:
+            break
+    with pytest.raises(ValueError, match="Invalid action"):
+        env.step([0, 9, 0, 0])
