@@ -43,6 +43,10 @@ constexpr int kScalInts = MAPF_NUM_COUNTERS;  // 16 int32 = 64 B per env
 constexpr uint32_t kNoCell = 0xFFFFu;         // "no target"
 constexpr uint32_t kIdleCell = 0xFFFEu;       // cell of a lane that holds no agent (row 255: far from any grid)
 constexpr uint32_t kIdleGoal = 0xFFFDu;
+// Obstacle rows are padded so that no bounds logic is needed: kRowPad all-ones sentinel rows above and below
+// each env's rows in LDS, and (when W <= 64 - 2*kRowPad: Io::col_pad = kRowPad) kRowPad sentinel bits at the
+// low end of every row; bits beyond the grid width are ones as well.
+constexpr int kRowPad = 5;  // = MAPF_MAX_SENSOR_RANGE
 
 // Engine constants, resident in device memory and read through a __restrict__ pointer (scalar loads
 // at the point of use; a by-value struct this size is held in SGPRs for the whole kernel and spills).
@@ -76,6 +80,7 @@ struct Io {
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
     // hot scalars (copies of the Params fields every launch needs before its first memory access)
     int B, H, W, eps_floor, steps_per_episode;
+    int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 54), else 0
     float den_r, den_c;
     int lds_tab_off, lds_stage_off, lds_scratch_off;
     const int8_t *actions;
@@ -252,8 +257,10 @@ struct WMask<128> {
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo, hi & ~o.hi}; }
 };
 
-// V bits of an obstacle row starting at column c0 (may be negative / run past 63); outside = 1
-__device__ __forceinline__ uint32_t row_window(uint64_t ext, int c0, int V) {
+// V bits of an obstacle row starting at column c0 (may be negative / run past 63); outside = 1.
+// col_pad != 0: the row carries col_pad sentinel bits below column 0 and ones above the grid, so one shift does it.
+__device__ __forceinline__ uint32_t row_window(uint64_t ext, int c0, int V, int col_pad) {
+    if (col_pad) return (uint32_t)(ext >> (c0 + col_pad)) & ((1u << V) - 1u);
     uint64_t w;
     if (c0 >= 0) {
         w = ext >> c0;
@@ -393,23 +400,30 @@ __device__ __forceinline__ void store_scal(int *scal, int env, const int *sc) {
     store_state16(sp + 2, make_uint4(sc[8], sc[9], sc[10], sc[11]));
 }
 
+// obstacle rows of the wave's envs -> LDS, env g at lrows[g * (H + 2*kRowPad) + kRowPad + r]; the pad rows are
+// all ones.  Lane (g, a) fetches rows a, a + LPE, ... of its own env.
+template <int LPE>
 __device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
                                                  int ngroups) {
-    const int total = ngroups * H;
-    const uint64_t *src = grid_rows + (size_t)env0 * H;
-    for (int k0 = 0; k0 < total; k0 += 256) {
+    const int grp = lane / LPE, a = lane % LPE;
+    const int stride = H + 2 * kRowPad;
+    uint64_t *dst = lrows + grp * stride;
+    const bool ok = grp < ngroups;
+    const uint64_t *src = grid_rows + (size_t)(env0 + (ok ? grp : 0)) * H;
+    for (int r0 = 0; r0 < H; r0 += 4 * LPE) {
         uint64_t t[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int idx = k0 + u * 64 + lane;
-            t[u] = idx < total ? src[idx] : 0ull;
+            const int r = r0 + u * LPE + a;
+            t[u] = (ok && r < H) ? src[r] : ~0ull;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            int idx = k0 + u * 64 + lane;
-            if (idx < total) lrows[idx] = t[u];
+            const int r = r0 + u * LPE + a;
+            if (r < H) dst[kRowPad + r] = t[u];
         }
     }
+    for (int k = a; k < 2 * kRowPad; k += LPE) dst[k < kRowPad ? k : H + k] = ~0ull;
 }
 
 __device__ __forceinline__ void raise_error(const Params &p, int code, int env, int agent, int value) {
@@ -503,14 +517,11 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     WMask<MW> obst, agm, goals;
     obst.clear(); agm.clear(); goals.clear();
 
+    // lrows points at the env's row 0; kRowPad sentinel rows sit on either side, so no bounds checks
     uint64_t rows[MAXV];
+    const int rbase = is_agent ? r0 : 0;
 #pragma unroll
-    for (int d = 0; d < MAXV; d++) {
-        const int r = r0 + d;
-        const bool in = (d < V) && r >= 0 && r < io.H && is_agent;
-        const uint64_t v = lrows[in ? r : 0];
-        rows[d] = in ? v : ~0ull;
-    }
+    for (int d = 0; d < MAXV; d++) rows[d] = (d < V) ? lrows[rbase + d] : ~0ull;
 
     uint32_t nbr_lo = 0, nbr_hi = 0;
     int sum_biased = 0, same_cell = 0;
@@ -551,7 +562,7 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
 
 #pragma unroll
     for (int d = 0; d < MAXV; d++) {
-        if (d < V) obst.or_row(row_window(rows[d], c0, V), d * V);
+        if (d < V) obst.or_row(row_window(rows[d], c0, V, io.col_pad), d * V);
     }
     const int ctr = sr * V + sr;
     agm.clear_bit(ctr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
@@ -807,7 +818,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         tabg[a] = static_entry(st.pos, st.goal);
         wave_lds_sync();
         PairOut po;
-        observe<K, LPE, MW, false>(p, io, lrows + grp * io.H, tabg, stage + (size_t)(grp * N + a) * K::L(p),
+        observe<K, LPE, MW, false>(p, io, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, stage + (size_t)(grp * N + a) * K::L(p),
                                    is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
         wave_lds_sync();
     }
@@ -846,7 +857,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     const int N = K::N(p);
     const bool is_agent = env_ok && a < N;
 
-    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     int sc[12];
@@ -881,14 +892,14 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p);
     const bool is_agent = env_ok && a < N;
-    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     uint4 *tabg = l.tab + grp * LPE;
     tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
     PairOut po;
-    observe<K, LPE, MW, false>(p, io, l.rows + grp * io.H, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
+    observe<K, LPE, MW, false>(p, io, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
                                st.pos, st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
     wave_lds_sync();
     flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
@@ -914,7 +925,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
     uint4 *tabg = l.tab + grp * LPE;
-    const uint64_t *myrows = l.rows + grp * H;
+    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
     const bool dist_in_rec = lw <= 16;  // goal-distance history lives in the agent record
 
     // ---- invalid action: the reference raises mid-loop, after the agents before the bad one were
@@ -938,9 +949,10 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
     const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
     const int tr = r_old + dr, tc = c_old + dc;
-    const bool inb = tr >= 0 && tr < H && tc >= 0 && tc < W;
-    const uint64_t trow = (live && inb) ? myrows[tr] : ~0ull;
-    const bool want = live && act != 0 && inb && !((trow >> tc) & 1ull);
+    // rows -1 and H are sentinel rows; with col_pad the columns -1 and W are sentinel bits too
+    const uint64_t trow = live ? myrows[tr] : ~0ull;
+    const bool col_ok = io.col_pad != 0 || (tc >= 0 && tc < W);
+    const bool want = live && act != 0 && col_ok && !((trow >> ((tc + io.col_pad) & 63)) & 1ull);
     const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
     // intended_next (MA-env:514-515) in the (+1,+1) encoding; may lie outside the grid
     const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
@@ -1259,7 +1271,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     int act = (full || is_agent) ? (int)io.actions[(size_t)env * N + a] : 0;
     int sc[12];
     load_scal(io.scal, env, sc);
-    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     wave_lds_sync();
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
@@ -1304,7 +1316,7 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
     load_lane(io.agents + (size_t)env * N + a, full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
-    load_rows_to_lds(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     wave_lds_sync();
 
     const size_t BN = (size_t)io.B * N;
@@ -1342,6 +1354,7 @@ struct CteIo {
     int *scal;
     const uint64_t *grid_rows;
     int B, H, W, steps_per_episode;
+    int col_pad;
     int lds_tab_off, lds_stage_off, lds_scratch_off;
     double blocking_penalty, move_after_goal_penalty;
     const int8_t *actions;
@@ -1361,7 +1374,7 @@ __device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const 
     const int H = io.H, W = io.W, HW = H * W;
     if (env_ok) {
         for (int r = 0; r < H; r++) {
-            const uint64_t bits = lrows[r];
+            const uint64_t bits = lrows[r] >> io.col_pad;
             for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
         }
     }
@@ -1444,7 +1457,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
     const int row_len = io.H * io.W + 5 * N;
-    load_rows_to_lds(io.grid_rows, io.H, lrows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, io.H, lrows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
@@ -1455,7 +1468,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
         st.flags = 0;
     }
     if (io.obs) {
-        cte_observe<LPE>(io, N, lrows + grp * io.H, stage + (size_t)grp * row_len, env_ok, is_agent, a, st.pos, st.goal);
+        cte_observe<LPE>(io, N, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, stage + (size_t)grp * row_len, env_ok, is_agent, a, st.pos, st.goal);
         Io fio;
         fio.obs = io.obs;
         fio.final_obs = nullptr;
@@ -1486,10 +1499,10 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
     const bool is_agent = env_ok && a < N;
     const int row_len = H * W + 5 * N;
     uint4 *tabg = tab + grp * LPE;
-    const uint64_t *myrows = lrows + grp * H;
+    const uint64_t *myrows = lrows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = stage + (size_t)grp * row_len;
 
-    load_rows_to_lds(io.grid_rows, H, lrows, lane, env0, ngroups);
+    load_rows_to_lds<LPE>(io.grid_rows, H, lrows, lane, env0, ngroups);
     Lane st;
     load_lane(io.agents + (size_t)env * N + a, is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
@@ -1510,9 +1523,9 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
     const uint32_t old = st.pos;
     const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0), dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
     const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
-    const bool inb = tr >= 0 && tr < H && tc >= 0 && tc < W;
-    const uint64_t trow = (live && inb) ? myrows[tr] : ~0ull;
-    const bool want = live && act != 0 && inb && !((trow >> tc) & 1ull);
+    const uint64_t trow = live ? myrows[tr] : ~0ull;
+    const bool col_ok = io.col_pad != 0 || (tc >= 0 && tc < W);
+    const bool want = live && act != 0 && col_ok && !((trow >> ((tc + io.col_pad) & 63)) & 1ull);
     const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
     const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
     uint32_t cur = old;

@@ -55,6 +55,7 @@ struct mapf_engine {
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     bool cte = false;  // single-agent (CTE) variant
+    int col_pad = 0;   // kRowPad when W <= 64 - 2*kRowPad
     double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
     int blocks = 0;
     int lds_bytes = 0;
@@ -238,6 +239,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     mapf_engine *e = new mapf_engine();
     e->cfg = c;
     e->cte = cte;
+    e->col_pad = (c.width <= 64 - 2 * kRowPad) ? kRowPad : 0;
     e->lpe = lpe;
     {
         const int vv = (2 * c.sensor_range + 1) * (2 * c.sensor_range + 1);
@@ -278,7 +280,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     }
     p.scratch_i16 = (p.hash_cap + 2 * N + 1) & ~1;
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
-    const int rows_bytes = ((G * H * 8) + 15) & ~15;
+    const int rows_bytes = ((G * (H + 2 * kRowPad) * 8) + 15) & ~15;  // kRowPad sentinel rows on either side
     const int tab_bytes = 64 * 16;  // one 16-byte entry per lane
     const int stage_bytes = ((G * (cte ? (H * W + 5 * N) : N * p.L) * 4) + 15) & ~15;
     const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
@@ -364,7 +366,9 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
     std::vector<uint64_t> rows((size_t)B * H);
     std::vector<uint16_t> cells((size_t)B * HW, 0), rank((size_t)B * HW, 0);
     std::vector<int> nfree(B);
-    const uint64_t hi = W >= 64 ? 0ull : (~0ull << W);  // columns >= W read as obstacle
+    // low sentinel bits when they fit (Io::col_pad), ones above the grid: out-of-bounds columns read as obstacle
+    const int pad = e->col_pad;
+    const uint64_t hi = (W + pad >= 64 ? 0ull : (~0ull << (W + pad))) | ((1ull << pad) - 1ull);
     for (int b = 0; b < B; b++) {
         const uint8_t *g = grids + (shared ? 0 : (size_t)b * HW);
         int f = 0;
@@ -372,7 +376,7 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
             uint64_t bits = hi;
             for (int c = 0; c < W; c++) {
                 if (g[r * W + c] != 0) {
-                    bits |= 1ull << c;
+                    bits |= 1ull << (c + pad);
                 } else {  // _free_positions = argwhere(grid == 0), row-major (MA-env:82)
                     cells[(size_t)b * HW + f] = (uint16_t)((r << 8) | c);
                     rank[(size_t)b * HW + r * W + c] = (uint16_t)f;
@@ -553,6 +557,7 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     io.B = e->p.B;
     io.H = e->p.H;
     io.W = e->p.W;
+    io.col_pad = e->col_pad;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -581,6 +586,7 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.B = e->p.B;
     io.H = e->p.H;
     io.W = e->p.W;
+    io.col_pad = e->col_pad;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -617,6 +623,7 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     io.B = e->p.B;
     io.H = e->p.H;
     io.W = e->p.W;
+    io.col_pad = e->col_pad;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -646,6 +653,7 @@ static CteIo make_cte_io(const mapf_engine *e) {
     io.B = e->p.B;
     io.H = e->p.H;
     io.W = e->p.W;
+    io.col_pad = e->col_pad;
     io.steps_per_episode = e->p.steps_per_episode;
     io.lds_tab_off = e->p.lds_tab_off;
     io.lds_stage_off = e->p.lds_stage_off;
@@ -722,6 +730,7 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.B = e->p.B;
     io.H = e->p.H;
     io.W = e->p.W;
+    io.col_pad = e->col_pad;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
