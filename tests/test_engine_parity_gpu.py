@@ -342,3 +342,36 @@ def test_episode_metrics_match_what_the_callbacks_would_log(lifelong):
         assert want[ACC_SUCCESSES] > 0 and m["success_rate"] == want[ACC_SUCCESSES] / want[ACC_EPISODES]
         assert "throughput" not in m
     assert np.array_equal(eng.env.episode_sums(reset=True), want) and eng.env.episode_sums().sum() == 0
+
+
+def test_randomized_configuration_fuzz_engine_vs_oracle():
+    """Random shapes / flags / windows / episode lengths / group widths: every combination must stay bit-exact.
+    (Seeded: the same 40 configurations every run.)"""
+    rng = np.random.default_rng(20260101)
+    for case in range(40):
+        H, W = int(rng.integers(1, 65)), int(rng.integers(2, 65))
+        N = int(rng.integers(1, min(64, max(1, (H * W) // 3)) + 1))
+        sr = int(rng.integers(0, 6))
+        cfg = {
+            "env_name": "synthetic", "num_agents": N, "sensor_range": sr,
+            "steps_per_episode": int(rng.integers(3, 70)),
+            "normalize_goal_delta": bool(rng.integers(0, 2)), "include_goal_distance": bool(rng.integers(0, 2)),
+            "include_action_mask_in_obs": bool(rng.integers(0, 2)),
+            "include_blocking_pressure_in_obs": bool(rng.integers(0, 2)),
+            "lifelong_mapf": bool(rng.integers(0, 2)), "enable_lock_metrics": bool(rng.integers(0, 4) > 0),
+            "deadlock_window_steps": int(rng.integers(1, 65)), "livelock_window_steps": int(rng.integers(1, 65)),
+            "lock_nearby_manhattan": int(rng.integers(1, 6)), "lock_min_neighbors": int(rng.integers(1, 4)),
+            "lock_progress_epsilon": float(rng.choice([0, 0.5, 1, 2, -1, 3.7])),
+        }
+        B = int(rng.integers(1, 40))
+        density = float(rng.choice([0.0, 0.1, 0.3]))
+        grids = synth_grids(B, H, W, density, N, base_seed=int(rng.integers(0, 10**6)))
+        seeds = [int(x) for x in rng.integers(0, 10**6, size=B)]
+        lanes = [l for l in (4, 8, 16, 32, 64) if l >= N]
+        extra = {"lanes_per_env": int(rng.choice(lanes))} if rng.random() < 0.5 else {}
+        p = rng.dirichlet(np.ones(5))
+        acts = rng.choice(5, size=(90, B, N), p=p).astype(np.int8)
+        try:
+            compare_steppers(EngineStepper(grids, cfg, seeds=seeds, **extra), OracleStepper(grids, cfg, seeds=seeds), acts)
+        except AssertionError as exc:
+            raise AssertionError(f"fuzz case {case}: cfg={cfg} B={B} HxW={H}x{W} density={density} extra={extra}: {exc}") from exc

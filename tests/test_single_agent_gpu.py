@@ -72,3 +72,25 @@ def test_single_agent_dropin_class_like_the_reference_dtype_test():
             break
     with pytest.raises(ValueError, match="Invalid action"):
         env.step([0, 9, 0, 0])
+
+
+def test_cte_randomized_configuration_fuzz():
+    rng = np.random.default_rng(77)
+    for case in range(15):
+        H, W = int(rng.integers(2, 65)), int(rng.integers(2, 65))
+        N = int(rng.integers(1, min(64, max(1, (H * W) // 4)) + 1))
+        cfg = {"env_name": "synthetic", "num_agents": N, "steps_per_episode": int(rng.integers(3, 50)),
+               "blocking_penalty": float(rng.choice([-0.2, -0.3, -1.0])),
+               "move_after_goal_penalty": float(rng.choice([-0.05, -0.07, 0.0]))}
+        B = int(rng.integers(1, 30))
+        grids = synth_grids(B, H, W, float(rng.choice([0.0, 0.2])), N, base_seed=int(rng.integers(0, 10**6)))
+        seeds = [int(x) for x in rng.integers(0, 10**6, size=B)]
+        a, b = CteEngineStepper(grids, cfg, seeds=seeds), CteOracleStepper(grids, cfg, seeds=seeds)
+        _eq(f"case {case} reset", a.reset(), b.reset())
+        p = rng.dirichlet(np.ones(5))
+        for t in range(70):
+            acts = rng.choice(5, size=(B, N), p=p).astype(np.int8)
+            ra, rb = a.step(acts), b.step(acts)
+            for k in ("obs", "reward", "terminated", "truncated", "info"):
+                _eq(f"case {case} {cfg} {H}x{W} {k}", ra[k], rb[k], t)
+        _eq(f"case {case} rng", a.rng_words(), b.rng_words())
