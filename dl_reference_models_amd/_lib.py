@@ -101,6 +101,11 @@ def load():
             f"{so_path} is missing: build it with `python -m dl_reference_models_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback."
         )
+    # torch first: it ships its own HIP runtime (libamdhip64) and must be the one that gets loaded; the engine
+    # library then binds to that same runtime instead of pulling in a second copy from /opt/rocm (with two
+    # runtimes in one process the later one finds no device)
+    import torch  # noqa: F401
+
     L = C.CDLL(so_path)
     vp, i32 = C.c_void_p, C.c_int32
     L.mapf_version.restype = C.c_uint32
