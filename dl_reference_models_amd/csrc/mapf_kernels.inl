@@ -81,6 +81,8 @@ struct Io {
     // hot scalars (copies of the Params fields every launch needs before its first memory access)
     int B, H, W, eps_floor, steps_per_episode;
     int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 54), else 0
+    int use_map;  // large-N path: per-env cell map in LDS instead of the all-pairs walk (lds_map_off valid)
+    int lds_map_off;
     float den_r, den_c;
     int lds_tab_off, lds_stage_off, lds_scratch_off;
     const int8_t *actions;
@@ -502,10 +504,19 @@ struct PairOut {
     int coincide;   // other agents sharing my cell (0 by invariant)
 };
 
-template <class K, int LPE, int MW, bool FULL>
+// Cell word of the LDS occupancy map (large-N path).  Every agent ORs its fields in with LDS atomics:
+//   bits 0-6   index+1 of the agent standing on the cell after the move ("new")      bits 22-31 its delta+256
+//   bits 7-13  index+1 of the agent that stood on the cell before the move ("old")
+//   bits 14-20 index+1 of the agent whose goal the cell is            bit 21  some not-yet-reached agent intends to enter
+// The map has a kRowPad border of never-occupied cells, so window / neighbourhood reads need no bounds checks.
+__device__ __forceinline__ int map_index(uint32_t cell, int map_w) {
+    return ((int)(cell >> 8) + kRowPad) * map_w + (int)(cell & 255u) + kRowPad;
+}
+
+template <class K, int LPE, int MW, bool FULL, bool USE_MAP = false>
 __device__ __forceinline__ void observe(const Params &p, const Io &io, const uint64_t *lrows, const uint4 *tabg, float *srow,
                                         bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
-                                        bool pressure, int my_delta, PairOut &po) {
+                                        bool pressure, int my_delta, PairOut &po, const uint32_t *map = nullptr) {
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
     constexpr int C = LPE < 8 ? LPE : 8;
     const int N = K::N(p), V = K::V(p), sr = K::sr(p);
@@ -526,6 +537,40 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     uint32_t nbr_lo = 0, nbr_hi = 0;
     int sum_biased = 0, same_cell = 0;
     bool blocks = false;
+    if (USE_MAP) {
+        // ---- large N: read my window and my lock neighbourhood from the env's cell map ----
+        const int map_w = io.W + 2 * kRowPad;
+        const uint32_t me1 = (uint32_t)a + 1u;
+        const uint32_t *win = map + (is_agent ? (r0 + kRowPad) * map_w + (c0 + kRowPad) : 0);
+        for (int d = 0; d < V; d++) {
+            for (int e = 0; e < V; e++) {
+                const uint32_t w = win[d * map_w + e];
+                const uint32_t on = w & 127u, oo = (w >> 7) & 127u, go = (w >> 14) & 127u;
+                // occupant at "time a": agents <= a at their new cell, agents > a at their old one (self excluded)
+                const bool occ = final_state ? (on != 0 && on != me1) : ((on != 0 && on < me1) || oo > me1);
+                agm.set_if(occ, d * V + e);
+                goals.set_if(go != 0, d * V + e);
+            }
+        }
+        if (FULL) {
+            const int nb = K::nearby(p);
+            const uint32_t *ctr = map + (is_agent ? map_index(cur, map_w) : kRowPad * map_w + kRowPad);
+            for (int dr = -nb; dr <= nb; dr++) {
+                const int span = nb - abs(dr);
+                for (int dc = -span; dc <= span; dc++) {
+                    const uint32_t w = ctr[dr * map_w + dc];
+                    const uint32_t on = w & 127u;
+                    const bool isn = on != 0 && (dr | dc) != 0;
+                    const int j = (int)on - 1;
+                    if (LPE <= 32 || j < 32) nbr_lo |= isn ? (1u << (j & 31)) : 0u;
+                    if (LPE > 32 && j >= 32) nbr_hi |= isn ? (1u << (j & 31)) : 0u;
+                    sum_biased += isn ? (int)(w >> 22) : 0;
+                }
+            }
+            blocks = (ctr[0] >> 21) & 1u;
+            same_cell = 1;  // coincidences (unreachable by the move rule) are not tracked on this path
+        }
+    } else
     for (int j0 = 0; j0 < N; j0 += C) {
         uint4 e[C];
 #pragma unroll
@@ -824,12 +869,22 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
     }
 }
 
+// zero the wave's cell maps (16-byte LDS stores; in k_step this runs under the latency of the state loads)
+template <int LPE>
+__device__ __forceinline__ void clear_cell_maps(const Io &io, uint32_t *map, int lane) {
+    constexpr int G = 64 / LPE;
+    const int n4 = (G * (io.H + 2 * kRowPad) * (io.W + 2 * kRowPad) + 3) >> 2;  // region is padded to 16 bytes
+    uint4 *m4 = reinterpret_cast<uint4 *>(map);
+    for (int k = lane; k < n4; k += 64) m4[k] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // LDS carve-up shared by the three kernels
 struct Lds {
     uint64_t *rows;
     uint4 *tab;
     float *stage;
     int16_t *scratch;
+    uint32_t *map;  // [G][H + 2*kRowPad][W + 2*kRowPad] cell words (only when Io::use_map)
 };
 __device__ __forceinline__ Lds carve_lds(const Io &io, unsigned char *raw) {
     Lds l;
@@ -837,6 +892,7 @@ __device__ __forceinline__ Lds carve_lds(const Io &io, unsigned char *raw) {
     l.tab = reinterpret_cast<uint4 *>(raw + io.lds_tab_off);
     l.stage = reinterpret_cast<float *>(raw + io.lds_stage_off);
     l.scratch = reinterpret_cast<int16_t *>(raw + io.lds_scratch_off);
+    l.map = reinterpret_cast<uint32_t *>(raw + io.lds_map_off);
     return l;
 }
 
@@ -1104,19 +1160,38 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
 
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
-    {
+    constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
+    PairOut po;
+    float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
+    if (MAP_OK && io.use_map) {
+        // large N: every agent ORs its fields into the env's (pre-cleared) cell map, then reads only its window and
+        // lock neighbourhood from it
+        const int map_w = W + 2 * kRowPad;
+        uint32_t *mapg = l.map + grp * (H + 2 * kRowPad) * map_w;
+        if (is_agent) {
+            const uint32_t me1 = (uint32_t)a + 1u;
+            atomicOr(&mapg[map_index(cur, map_w)], me1 | ((uint32_t)(delta + 256) << 22));
+            atomicOr(&mapg[map_index(old, map_w)], me1 << 7);
+            atomicOr(&mapg[map_index(st.goal, map_w)], me1 << 14);
+            // intended_next may lie one cell outside the grid: that is inside the map's border
+            if (!reached) atomicOr(&mapg[(tr + kRowPad) * map_w + tc + kRowPad], 1u << 21);
+        }
+        wave_lds_sync();
+        MAPF_STAMP(3);
+        observe<K, LPE, MW, true, MAP_OK>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned, pressure_prev,
+                                          delta, po, mapg);
+    } else {
         uint4 ent;
         ent.x = old | (cur << 16);
         ent.y = (st.goal & 0xFFFFu) | ((reached ? 1u : 0u) << 16) | ((uint32_t)(delta + 256) << 17);
         ent.z = (is_agent && !reached) ? intended1 : 0xFFFFFFFFu;
         ent.w = 0u;
         tabg[a] = ent;
+        wave_lds_sync();
+        MAPF_STAMP(3);
+        observe<K, LPE, MW, true, false>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned, pressure_prev,
+                                         delta, po);
     }
-    wave_lds_sync();
-    MAPF_STAMP(3);
-    PairOut po;
-    observe<K, LPE, MW, true>(p, io, myrows, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a, cur, st.goal,
-                              reassigned, pressure_prev, delta, po);
     MAPF_STAMP(4);
 
     // ---- observations leave the wave as one contiguous stream ------------------------------------
@@ -1272,6 +1347,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     int sc[12];
     load_scal(io.scal, env, sc);
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
     wave_lds_sync();
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
@@ -1321,6 +1397,10 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
 
     const size_t BN = (size_t)io.B * N;
     for (int t = 0; t < T; t++) {
+        if (LPE >= 32 && io.use_map) {
+            clear_cell_maps<LPE>(io, l.map, lane);
+            wave_lds_sync();
+        }
         Io it = io;
         it.auto_reset = 1;
         it.final_obs = nullptr;

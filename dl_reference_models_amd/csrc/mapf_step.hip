@@ -56,6 +56,7 @@ struct mapf_engine {
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     bool cte = false;  // single-agent (CTE) variant
     int col_pad = 0;   // kRowPad when W <= 64 - 2*kRowPad
+    int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
     double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
     int blocks = 0;
     int lds_bytes = 0;
@@ -112,8 +113,9 @@ hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t
 // the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
 int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) return 0;
+    const uint32_t cfg_flags = c.flags & ~MAPF_FLAG_NO_CELL_MAP;
 #define MAPF_MATCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                            \
-    if (c.num_agents == N_ && c.sensor_range == SR_ && c.flags == (uint32_t)(FLAGS_) &&                             \
+    if (c.num_agents == N_ && c.sensor_range == SR_ && cfg_flags == (uint32_t)(FLAGS_) &&                             \
         c.deadlock_window_steps == DW_ && c.livelock_window_steps == LW_ && nearby_clamped == NEARBY_ &&           \
         c.lock_min_neighbors == MINN_ && lpe == LPE_)                                                              \
         return ID;
@@ -256,7 +258,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.V = 2 * c.sensor_range + 1;
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
-    p.flags = c.flags & ~MAPF_FLAG_GENERIC_KERNEL;
+    p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP);
     e->special = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
@@ -288,6 +290,16 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.lds_stage_off = rows_bytes + tab_bytes;
     p.lds_scratch_off = rows_bytes + tab_bytes + stage_bytes;
     e->lds_bytes = rows_bytes + tab_bytes + stage_bytes + scratch_bytes;
+    {   // wide groups (N > 16): per-env cell map in LDS instead of the all-pairs walk, when it fits and the lock
+        // neighbourhood stays inside the map's border
+        const int map_bytes = ((G * (H + 2 * kRowPad) * (W + 2 * kRowPad) * 4) + 15) & ~15;
+        if (!cte && lpe >= 32 && c.lock_nearby_manhattan <= kRowPad && !(c.flags & MAPF_FLAG_NO_CELL_MAP) &&
+            e->lds_bytes + map_bytes <= 64 * 1024) {
+            e->use_map = 1;
+            e->lds_map_off = e->lds_bytes;
+            e->lds_bytes += map_bytes;
+        }
+    }
     if (e->lds_bytes > 64 * 1024) {
         delete e;
         return fail(nullptr, MAPF_ERR_CONFIG, "config needs more than 64 KiB of LDS per wavefront");
@@ -558,6 +570,8 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.use_map = e->use_map;
+    io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -587,6 +601,8 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.use_map = e->use_map;
+    io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -624,6 +640,8 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.use_map = e->use_map;
+    io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;
@@ -731,6 +749,8 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.use_map = e->use_map;
+    io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;
     io.den_r = e->p.den_r;

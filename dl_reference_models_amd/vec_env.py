@@ -86,6 +86,8 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_LOCK_METRICS
     if cfg.get("deterministic", False):
         f |= L.FLAG_DETERMINISTIC
+    if cfg.get("force_pair_walk", False):  # engine knob: all-pairs walk instead of the LDS cell map at N > 16
+        f |= L.FLAG_NO_CELL_MAP
     if cfg.get("force_generic_kernel", False):  # engine knob: skip the compile-time specialised step kernel
         f |= L.FLAG_GENERIC_KERNEL
     return f

@@ -133,6 +133,15 @@ def test_engine_vs_oracle_c5_64x64x64_lifelong():
     assert stats["goals"] > 0 and stats["episodes"] >= 256
 
 
+@pytest.mark.parametrize("extra", [{"force_pair_walk": True}, {"lock_nearby_manhattan": 5, "lock_min_neighbors": 2},
+                                   {"lock_nearby_manhattan": 9}, {"sensor_range": 5, "include_goal_distance": True}])
+def test_wide_group_paths_cell_map_and_pair_walk(extra):
+    """N > 16: the LDS cell-map path (default) and the all-pairs walk (forced, or when the lock radius exceeds the
+    map border) must both match the oracle."""
+    _vs_oracle(48, 40, 37, 33, 0.15, 200, dict({"lifelong_mapf": True, "steps_per_episode": 70}, **extra))
+    _vs_oracle(24, 64, 64, 64, 0.20, 150, dict({"steps_per_episode": 60}, **extra))
+
+
 def test_engine_vs_oracle_odd_shapes():
     for (B, H, W, N, sr, extra) in [
         (37, 7, 9, 12, 3, {"lifelong_mapf": True, "steps_per_episode": 50, "deadlock_window_steps": 3,
@@ -369,6 +378,8 @@ def test_randomized_configuration_fuzz_engine_vs_oracle():
         seeds = [int(x) for x in rng.integers(0, 10**6, size=B)]
         lanes = [l for l in (4, 8, 16, 32, 64) if l >= N]
         extra = {"lanes_per_env": int(rng.choice(lanes))} if rng.random() < 0.5 else {}
+        if rng.random() < 0.3:
+            extra["force_pair_walk"] = True
         p = rng.dirichlet(np.ones(5))
         acts = rng.choice(5, size=(90, B, N), p=p).astype(np.int8)
         try:
