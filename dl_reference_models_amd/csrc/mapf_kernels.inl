@@ -488,6 +488,59 @@ __device__ __forceinline__ uint32_t resolve_moves(const Params &p, uint2 *tabg, 
     return moved ? tgt : old;
 }
 
+// Cell word of the LDS occupancy map (large-N path).  Every agent ORs its fields in with LDS atomics:
+//   bits 0-6   index+1 of the agent standing on the cell after the move ("new")      bits 22-31 its delta+256
+//   bits 7-13  index+1 of the agent that stood on the cell before the move ("old")
+//   bits 14-20 index+1 of the agent whose goal the cell is            bit 21  some not-yet-reached agent intends to enter
+// The map has a kRowPad border of never-occupied cells, so window / neighbourhood reads need no bounds checks.
+__device__ __forceinline__ int map_index(uint32_t cell, int map_w) {
+    return ((int)(cell >> 8) + kRowPad) * map_w + (int)(cell & 255u) + kRowPad;
+}
+
+// The same resolution for wide groups with the LDS cell map (owner-old fields already written): the occupant of
+// the target is one map read, and a per-cell contender count (LDS atomic add into the not-yet-used delta field)
+// tells which agents are contended at all; only those are walked to build the lower-index contender sets.
+template <class K, int LPE>
+__device__ __forceinline__ uint32_t resolve_moves_map(const Params &p, uint32_t *mapg, int map_w, int lane, int a,
+                                                      uint32_t old, uint32_t tgt) {
+    using gm_t = typename GMask<LPE>::type;
+    const bool want = tgt != kNoCell;
+    uint32_t *tcell = mapg + (want ? map_index(tgt, map_w) : 0);
+    if (want) atomicAdd(tcell, 1u << 22);
+    wave_lds_sync();
+    const uint32_t w = want ? *tcell : 0u;
+    const uint32_t occ1 = (w >> 7) & 127u;  // index+1 of the agent standing on my target (0 = none)
+    const bool contended = want && ((w >> 22) & 7u) > 1u;
+    gm_t cont = 0;
+    uint64_t u = fold_groups<LPE>(__ballot(contended));
+    while (u) {  // typically a handful of agents, not N
+        const int j = (int)__builtin_ctzll(u);
+        u &= u - 1;
+        const uint32_t tj = gshfl<LPE>(contended ? tgt : kNoCell, j);
+        cont |= (want && j < a && tj == tgt) ? ((gm_t)1 << j) : 0;
+    }
+    const gm_t below = ((gm_t)1 << a) - 1;
+    const gm_t occ_bit = occ1 ? ((gm_t)1 << (occ1 - 1)) : 0;
+    const gm_t occ_low = occ_bit & below;
+    const bool occ_high = (occ_bit & ~below) != 0;
+    const gm_t dep = cont | occ_low;
+    bool resolved = !want, moved = false;
+    gm_t R = gballot_n<LPE>(resolved, lane), M = 0;
+#pragma unroll 1
+    for (int it = 0; it <= K::N(p); it++) {
+        if (__all(resolved)) break;
+        if (!resolved && (dep & ~R) == 0) {
+            moved = !(occ_high || (occ_low & ~M) != 0 || (cont & M) != 0);
+            resolved = true;
+        }
+        R = gballot_n<LPE>(resolved, lane);
+        M = gballot_n<LPE>(moved, lane);
+    }
+    if (want) atomicAnd(tcell, ~(7u << 22));  // give the field back: it receives the distance deltas next
+    wave_lds_sync();
+    return moved ? tgt : old;
+}
+
 // ------------------------------------------------------------------------------------------------
 // observation of every agent lane -> LDS staging row (MA-env:707-747 get_obs, :749-773 mask,
 // :306-335 flatten), fused with the other all-pairs work of a step when FULL: neighbour sets of
@@ -503,15 +556,6 @@ struct PairOut {
     bool blocks;    // some not-yet-reached agent intended to enter my cell
     int coincide;   // other agents sharing my cell (0 by invariant)
 };
-
-// Cell word of the LDS occupancy map (large-N path).  Every agent ORs its fields in with LDS atomics:
-//   bits 0-6   index+1 of the agent standing on the cell after the move ("new")      bits 22-31 its delta+256
-//   bits 7-13  index+1 of the agent that stood on the cell before the move ("old")
-//   bits 14-20 index+1 of the agent whose goal the cell is            bit 21  some not-yet-reached agent intends to enter
-// The map has a kRowPad border of never-occupied cells, so window / neighbourhood reads need no bounds checks.
-__device__ __forceinline__ int map_index(uint32_t cell, int map_w) {
-    return ((int)(cell >> 8) + kRowPad) * map_w + (int)(cell & 255u) + kRowPad;
-}
 
 template <class K, int LPE, int MW, bool FULL, bool USE_MAP = false>
 __device__ __forceinline__ void observe(const Params &p, const Io &io, const uint64_t *lrows, const uint4 *tabg, float *srow,
@@ -541,30 +585,53 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
         // ---- large N: read my window and my lock neighbourhood from the env's cell map ----
         const int map_w = io.W + 2 * kRowPad;
         const uint32_t me1 = (uint32_t)a + 1u;
+        // occupant at "time a": agents <= a at their new cell, agents > a at their old one.  As two thresholds (no
+        // per-cell branch on final_state): a new-cell owner o counts if 1 <= o < new_lim, i.e. (o - 1) < (new_lim - 1)
+        // unsigned, an old-cell owner if > old_lim.  My own cell (the centre) is cleared afterwards.
+        const uint32_t new_lim1 = final_state ? 127u : me1 - 1u;
+        const uint32_t old_lim = final_state ? 127u : me1;
         const uint32_t *win = map + (is_agent ? (r0 + kRowPad) * map_w + (c0 + kRowPad) : 0);
         for (int d = 0; d < V; d++) {
-            for (int e = 0; e < V; e++) {
-                const uint32_t w = win[d * map_w + e];
-                const uint32_t on = w & 127u, oo = (w >> 7) & 127u, go = (w >> 14) & 127u;
-                // occupant at "time a": agents <= a at their new cell, agents > a at their old one (self excluded)
-                const bool occ = final_state ? (on != 0 && on != me1) : ((on != 0 && on < me1) || oo > me1);
-                agm.set_if(occ, d * V + e);
-                goals.set_if(go != 0, d * V + e);
+            uint32_t wrow[MAXV];  // one window row per round trip: the V reads are issued back to back
+#pragma unroll
+            for (int e = 0; e < MAXV; e++) wrow[e] = (e < V) ? win[d * map_w + e] : 0u;
+#pragma unroll
+            for (int e = 0; e < MAXV; e++) {
+                if (e < V) {
+                    const uint32_t w = wrow[e];
+                    const uint32_t on = w & 127u, oo = (w >> 7) & 127u, go = (w >> 14) & 127u;
+                    const bool occ = (on - 1u) < new_lim1 || oo > old_lim;
+                    agm.set_if(occ, d * V + e);
+                    goals.set_if(go != 0, d * V + e);
+                }
             }
         }
         if (FULL) {
             const int nb = K::nearby(p);
             const uint32_t *ctr = map + (is_agent ? map_index(cur, map_w) : kRowPad * map_w + kRowPad);
-            for (int dr = -nb; dr <= nb; dr++) {
-                const int span = nb - abs(dr);
-                for (int dc = -span; dc <= span; dc++) {
-                    const uint32_t w = ctr[dr * map_w + dc];
-                    const uint32_t on = w & 127u;
-                    const bool isn = on != 0 && (dr | dc) != 0;
-                    const int j = (int)on - 1;
-                    if (LPE <= 32 || j < 32) nbr_lo |= isn ? (1u << (j & 31)) : 0u;
-                    if (LPE > 32 && j >= 32) nbr_hi |= isn ? (1u << (j & 31)) : 0u;
-                    sum_biased += isn ? (int)(w >> 22) : 0;
+            auto visit = [&](const uint32_t w) {  // w = cell word of a neighbourhood cell (centre excluded by the caller)
+                const uint32_t on = w & 127u;
+                const bool isn = on != 0;
+                const int j = (int)on - 1;
+                if (LPE <= 32 || j < 32) nbr_lo |= isn ? (1u << (j & 31)) : 0u;
+                if (LPE > 32 && j >= 32) nbr_hi |= isn ? (1u << (j & 31)) : 0u;
+                sum_biased += isn ? (int)(w >> 22) : 0;
+            };
+            if (K::kFixed) {
+                // compile-time radius: the diamond is fully unrolled and pruned, all its reads are issued together
+#pragma unroll
+                for (int dr = -kRowPad; dr <= kRowPad; dr++) {
+#pragma unroll
+                    for (int dc = -kRowPad; dc <= kRowPad; dc++) {
+                        if (abs(dr) + abs(dc) <= nb && (dr | dc) != 0) visit(ctr[dr * map_w + dc]);
+                    }
+                }
+            } else {
+                for (int dr = -nb; dr <= nb; dr++) {
+                    const int span = nb - abs(dr);
+                    for (int dc = -span; dc <= span; dc++) {
+                        if ((dr | dc) != 0) visit(ctr[dr * map_w + dc]);
+                    }
                 }
             }
             blocks = (ctr[0] >> 21) & 1u;
@@ -1013,7 +1080,17 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     // intended_next (MA-env:514-515) in the (+1,+1) encoding; may lie outside the grid
     const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
     uint32_t cur = old;
-    if (__any(want)) cur = resolve_moves<K, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
+    constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
+    const bool use_map = MAP_OK && io.use_map;
+    const int map_w = W + 2 * kRowPad;
+    uint32_t *mapg = l.map + grp * (H + 2 * kRowPad) * map_w;
+    if (use_map) {
+        if (is_agent) atomicOr(&mapg[map_index(old, map_w)], ((uint32_t)a + 1u) << 7);  // owner-old field
+        if (__any(want)) cur = resolve_moves_map<K, LPE>(p, mapg, map_w, lane, a, old, tgt);
+        else wave_lds_sync();
+    } else if (__any(want)) {
+        cur = resolve_moves<K, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
+    }
     const bool moved = cur != old;
     MAPF_STAMP(2);
 
@@ -1160,18 +1237,14 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
 
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
-    constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
     PairOut po;
     float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
-    if (MAP_OK && io.use_map) {
-        // large N: every agent ORs its fields into the env's (pre-cleared) cell map, then reads only its window and
-        // lock neighbourhood from it
-        const int map_w = W + 2 * kRowPad;
-        uint32_t *mapg = l.map + grp * (H + 2 * kRowPad) * map_w;
+    if (use_map) {
+        // large N: every agent ORs its remaining fields into the env's cell map (owner-old went in before the move),
+        // then reads only its window and lock neighbourhood from it
         if (is_agent) {
             const uint32_t me1 = (uint32_t)a + 1u;
             atomicOr(&mapg[map_index(cur, map_w)], me1 | ((uint32_t)(delta + 256) << 22));
-            atomicOr(&mapg[map_index(old, map_w)], me1 << 7);
             atomicOr(&mapg[map_index(st.goal, map_w)], me1 << 14);
             // intended_next may lie one cell outside the grid: that is inside the map's border
             if (!reached) atomicOr(&mapg[(tr + kRowPad) * map_w + tc + kRowPad], 1u << 21);
