@@ -21,7 +21,10 @@ DEVICE_INCLUDES = [os.path.join(CSRC, "mapf_kernels.inl")]
 HEADERS = [os.path.join(ROOT, "include", "mapf_step.h")]
 
 # NOTE: no -ffast-math -- goal_delta needs the correctly rounded fp32 divide.
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value"]
+# -amdgpu-kernarg-preload-count: gfx950 delivers the first 16 kernarg dwords in SGPRs at wave launch, so the
+#   wave's first state loads do not sit behind a scalar-load round trip (Io is ordered hot-fields-first for it).
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def find_hipcc() -> str:

@@ -74,18 +74,22 @@ struct Params {
 // global-address-space pointers; pointers read out of Params are generic and compile to flat_* ops)
 // and the per-launch io tensors
 struct Io {
+    // --- first 14 dwords (with the Params pointer: 16): what the very first loads of a wave need; the library is
+    //     built with kernarg preload so these arrive in SGPRs at wave launch instead of through a scalar load ---
     AgentRec *agents;
     int *scal;
-    int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw (only when lw > 16)
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
-    // hot scalars (copies of the Params fields every launch needs before its first memory access)
-    int B, H, W, eps_floor, steps_per_episode;
+    const int8_t *actions;
+    int B, H, W;
     int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 54), else 0
+    // --- the rest ---
+    int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw (only when lw > 16)
+    // hot scalars (copies of the Params fields every launch needs before its first memory access)
+    int eps_floor, steps_per_episode;
     int use_map;  // large-N path: per-env cell map in LDS instead of the all-pairs walk (lds_map_off valid)
     int lds_map_off;
     float den_r, den_c;
     int lds_tab_off, lds_stage_off, lds_scratch_off;
-    const int8_t *actions;
     float *obs, *rewards;
     uint8_t *terminated, *truncated;
     float *info_all;
@@ -94,6 +98,14 @@ struct Io {
     const uint8_t *env_mask;
     int auto_reset;
 };
+
+// Scalar-cache warm-up, first statement of the hot kernels.  The compiler fetches kernel arguments and Params
+// fields lazily, one scalar load (and one full wait) per first use, so a wave would pay a chain of scalar-cache
+// misses spread through its prologue.  Demanding one dword of every 64-byte line here makes all those loads go
+// out in the first batch, under a single wait (the Params pointer itself arrives preloaded in SGPRs: build.py).
+__device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp, const Io &io) {
+    asm volatile("" ::"s"(io.eps_floor), "s"(io.truncated), "s"(io.auto_reset), "s"(pp->N), "s"(pp->HW), "s"(pp->ep_acc));
+}
 
 // In-kernel stamps (diagnostic build only; never in the shipped library): lane 0 of each wave records
 // s_memtime at phase boundaries of k_step into Params::dbg, which nothing else reads.
@@ -336,26 +348,20 @@ struct Lane {
     uint4 dist;  // 16 x uint8 goal-distance history
 };
 
+// `rec` must be readable for every lane (callers clamp the index of idle lanes to a real record): the three
+// 16-byte loads are unconditional, so they issue back to back with the wave's other loads instead of sitting in
+// an exec-masked branch with its own wait; idle lanes then replace what they read by the sentinels.
 __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
-    if (is_agent) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
-        uint4 q0 = rp[0], q1 = rp[1];
-        st.dist = rp[2];
-        st.pos = q0.x & 0xFFFFu;
-        st.goal = q0.x >> 16;
-        st.start = q0.y & 0xFFFFu;
-        st.flags = (q0.y >> 16) & 0xFFu;
-        st.moved = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
-        st.failed = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
-        st.progress = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
-    } else {
-        st.pos = kIdleCell;
-        st.goal = kIdleGoal;
-        st.start = kIdleCell;
-        st.flags = 0;
-        st.moved = st.failed = st.progress = 0;
-        st.dist = make_uint4(0, 0, 0, 0);
-    }
+    const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
+    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
+    st.dist = is_agent ? q2 : make_uint4(0, 0, 0, 0);
+    st.pos = is_agent ? (q0.x & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.goal = is_agent ? (q0.x >> 16) : (uint32_t)kIdleGoal;
+    st.start = is_agent ? (q0.y & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.flags = is_agent ? ((q0.y >> 16) & 0xFFu) : 0u;
+    st.moved = is_agent ? ((uint64_t)q0.z | ((uint64_t)q0.w << 32)) : 0ull;
+    st.failed = is_agent ? ((uint64_t)q1.x | ((uint64_t)q1.y << 32)) : 0ull;
+    st.progress = is_agent ? ((uint64_t)q1.z | ((uint64_t)q1.w << 32)) : 0ull;
 }
 
 // 16-byte state store; MAPF_STATE_STORE: 0 = plain (line stays in L2), 2 = sc1 write-through
@@ -403,29 +409,41 @@ __device__ __forceinline__ void store_scal(int *scal, int env, const int *sc) {
 }
 
 // obstacle rows of the wave's envs -> LDS, env g at lrows[g * (H + 2*kRowPad) + kRowPad + r]; the pad rows are
-// all ones.  Lane (g, a) fetches rows a, a + LPE, ... of its own env.
+// all ones.  Lane (g, a) fetches rows a, a + LPE, ... of its own env.  Split in two so that a kernel can issue
+// these loads together with its other state loads and only then wait: rows_issue() fetches the first 4*LPE rows
+// into registers, rows_commit() writes them (and any further rows of taller grids) to LDS.
+struct RowRegs {
+    uint64_t t[4];
+};
 template <int LPE>
-__device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
-                                                 int ngroups) {
+__device__ __forceinline__ void rows_issue(const uint64_t *grid_rows, int H, int lane, int env0, int ngroups, RowRegs &rr) {
+    const int grp = lane / LPE, a = lane % LPE;
+    const uint64_t *src = grid_rows + (size_t)(env0 + min(grp, ngroups - 1)) * H;
+#pragma unroll
+    for (int u = 0; u < 4; u++) rr.t[u] = src[min(u * LPE + a, H - 1)];  // clamped, unconditional; commit selects
+}
+template <int LPE>
+__device__ __forceinline__ void rows_commit(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
+                                            int ngroups, const RowRegs &rr) {
     const int grp = lane / LPE, a = lane % LPE;
     const int stride = H + 2 * kRowPad;
     uint64_t *dst = lrows + grp * stride;
     const bool ok = grp < ngroups;
     const uint64_t *src = grid_rows + (size_t)(env0 + (ok ? grp : 0)) * H;
-    for (int r0 = 0; r0 < H; r0 += 4 * LPE) {
-        uint64_t t[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int r = r0 + u * LPE + a;
-            t[u] = (ok && r < H) ? src[r] : ~0ull;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int r = r0 + u * LPE + a;
-            if (r < H) dst[kRowPad + r] = t[u];
-        }
+    for (int u = 0; u < 4; u++) {
+        const int r = u * LPE + a;
+        if (r < H) dst[kRowPad + r] = ok ? rr.t[u] : ~0ull;
     }
+    for (int r = 4 * LPE + a; r < H; r += LPE) dst[kRowPad + r] = ok ? src[r] : ~0ull;  // H > 4*LPE only
     for (int k = a; k < 2 * kRowPad; k += LPE) dst[k < kRowPad ? k : H + k] = ~0ull;
+}
+template <int LPE>
+__device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int H, uint64_t *lrows, int lane, int env0,
+                                                 int ngroups) {
+    RowRegs rr;
+    rows_issue<LPE>(grid_rows, H, lane, env0, ngroups, rr);
+    rows_commit<LPE>(grid_rows, H, lrows, lane, env0, ngroups, rr);
 }
 
 __device__ __forceinline__ void raise_error(const Params &p, int code, int env, int agent, int value) {
@@ -982,7 +1000,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
 
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
@@ -1017,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     const bool is_agent = env_ok && a < N;
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
     uint4 *tabg = l.tab + grp * LPE;
     tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
@@ -1400,6 +1418,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
 template <class K, int LPE, int MW>
 __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
     const Params &p = *pp;
+    warm_scalar_cache(pp, io);
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds l = carve_lds(io, lds_raw);
@@ -1413,14 +1432,18 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     const bool is_agent = env_ok && a < N;
 
     MAPF_STAMP(0);
-    // ---- loads: agent record, env scalars, action, distance ring, obstacle rows -> LDS; all in flight together
+    // ---- loads: agent record, action, env scalars, obstacle rows; every load is issued before the first wait
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, full || is_agent, st);
-    int act = (full || is_agent) ? (int)io.actions[(size_t)env * N + a] : 0;
+    RowRegs rr;
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
+    int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
+    act = (full || is_agent) ? act : 0;
     int sc[12];
     load_scal(io.scal, env, sc);
-    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+    rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+    __builtin_amdgcn_sched_barrier(0);  // keep the LDS work below from being hoisted between the loads
     if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
+    rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
     wave_lds_sync();
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
@@ -1449,6 +1472,7 @@ template <class K, int LPE, int MW>
 __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp, const Io io, const int T,
                                                   const int obs_mode) {
     const Params &p = *pp;
+    warm_scalar_cache(pp, io);
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds l = carve_lds(io, lds_raw);
@@ -1462,7 +1486,7 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
     const bool is_agent = env_ok && a < N;
 
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, full || is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
@@ -1612,7 +1636,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     const int row_len = io.H * io.W + 5 * N;
     load_rows_to_lds<LPE>(io.grid_rows, io.H, lrows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
     if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
@@ -1657,7 +1681,7 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
 
     load_rows_to_lds<LPE>(io.grid_rows, H, lrows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + a, is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
     int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
     wave_lds_sync();

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "gpurun_out", "libmapfstep_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
-                "-DMAPF_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so,
+                "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DMAPF_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so,
                 os.path.join(ROOT, "dl_reference_models_amd", "csrc", "mapf_step.hip")], check=True)
 os.environ["MAPF_LIB"] = so
 import torch
