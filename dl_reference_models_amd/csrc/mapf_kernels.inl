@@ -73,16 +73,20 @@ struct Params {
 // kernel arguments passed by value: the hot state arrays (as kernel arguments they are known to be
 // global-address-space pointers; pointers read out of Params are generic and compile to flat_* ops)
 // and the per-launch io tensors
-struct Io {
-    // --- first 14 dwords (with the Params pointer: 16): what the very first loads of a wave need; the library is
-    //     built with kernarg preload so these arrive in SGPRs at wave launch instead of through a scalar load ---
+// IoHead: what the first global loads of a wave need.  The step kernels take these 12 dwords (plus the Params
+// pointer: 14, the preload budget next to the kernarg segment pointer) as individual kernel arguments, because
+// only scalar and pointer arguments can be preloaded into SGPRs at wave launch (a by-value struct cannot): the
+// state loads then leave in the wave's first cycles instead of behind a scalar-load round trip (build.py,
+// -amdgpu-kernarg-preload-count).
+struct IoHead {
     AgentRec *agents;
     int *scal;
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
     const int8_t *actions;
     int B, H, W;
     int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 54), else 0
-    // --- the rest ---
+};
+struct IoTail {
     int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw (only when lw > 16)
     // hot scalars (copies of the Params fields every launch needs before its first memory access)
     int eps_floor, steps_per_episode;
@@ -98,12 +102,31 @@ struct Io {
     const uint8_t *env_mask;
     int auto_reset;
 };
+struct Io : IoHead, IoTail {};
+#define MAPF_IO_HEAD_PARAMS                                                                                          \
+    AgentRec *a_agents, int *a_scal, const uint64_t *a_grid_rows, const int8_t *a_actions, const int a_B, const int a_H, \
+        const int a_W, const int a_col_pad
+__device__ __forceinline__ Io join_io(AgentRec *agents, int *scal, const uint64_t *grid_rows, const int8_t *actions, int B,
+                                      int H, int W, int col_pad, const IoTail &tail) {
+    Io io;
+    static_cast<IoTail &>(io) = tail;
+    io.agents = agents;
+    io.scal = scal;
+    io.grid_rows = grid_rows;
+    io.actions = actions;
+    io.B = B;
+    io.H = H;
+    io.W = W;
+    io.col_pad = col_pad;
+    return io;
+}
+#define MAPF_IO_JOIN join_io(a_agents, a_scal, a_grid_rows, a_actions, a_B, a_H, a_W, a_col_pad, tail)
 
 // Scalar-cache warm-up, first statement of the hot kernels.  The compiler fetches kernel arguments and Params
 // fields lazily, one scalar load (and one full wait) per first use, so a wave would pay a chain of scalar-cache
 // misses spread through its prologue.  Demanding one dword of every 64-byte line here makes all those loads go
 // out in the first batch, under a single wait (the Params pointer itself arrives preloaded in SGPRs: build.py).
-__device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp, const Io &io) {
+__device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp, const IoTail &io) {
     asm volatile("" ::"s"(io.eps_floor), "s"(io.truncated), "s"(io.auto_reset), "s"(pp->N), "s"(pp->HW), "s"(pp->ep_acc));
 }
 
@@ -118,8 +141,29 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16 + (k)] = _t;       \
     } while (0)
+// wave entry time, taken before the first scalar load is waited for; written to slot 15 by MAPF_STAMP_ENTRY_STORE
+#define MAPF_STAMP_ENTRY()                                                              \
+    unsigned long long _t_entry;                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t_entry)::"memory")
+#define MAPF_STAMP_ENTRY_STORE()                                                        \
+    do {                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16 + 15] = _t_entry;  \
+    } while (0)
+// the same for the observation wave (lane 64 of a two-wave workgroup), slots 10..14
+#define MAPF_STAMP_W1(k)                                                                \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long _t;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)blockIdx.x * 16 + (k)] = _t;      \
+    } while (0)
 #else
 #define MAPF_STAMP(k) do { } while (0)
+#define MAPF_STAMP_W1(k) do { } while (0)
+#define MAPF_STAMP_ENTRY() do { } while (0)
+#define MAPF_STAMP_ENTRY_STORE() do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -271,17 +315,19 @@ struct WMask<128> {
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo, hi & ~o.hi}; }
 };
 
-// V bits of an obstacle row starting at column c0 (may be negative / run past 63); outside = 1.
-// col_pad != 0: the row carries col_pad sentinel bits below column 0 and ones above the grid, so one shift does it.
-__device__ __forceinline__ uint32_t row_window(uint64_t ext, int c0, int V, int col_pad) {
-    if (col_pad) return (uint32_t)(ext >> (c0 + col_pad)) & ((1u << V) - 1u);
-    uint64_t w;
-    if (c0 >= 0) {
-        w = ext >> c0;
-        if (c0 > 0) w |= ~0ull << (64 - c0);
-    } else {
-        w = (ext << (-c0)) | ((1ull << (-c0)) - 1ull);
-    }
+// V bits of an obstacle row starting at column c0; outside the grid = 1.
+// Padded rows (col_pad != 0, W <= 54): the row carries col_pad sentinel bits below column 0 and ones above the
+// grid, so one shift does it.
+__device__ __forceinline__ uint32_t row_window_padded(uint64_t ext, int c0, int V, int col_pad) {
+    return (uint32_t)(ext >> ((c0 + col_pad) & 63)) & ((1u << V) - 1u);
+}
+// Unpadded rows (W > 54): c0 may be negative or the window may run past bit 63.  Branch-free: both shift
+// directions are computed and selected (the compiler turns an if/else over 64-bit shifts into exec-mask branches).
+__device__ __forceinline__ uint32_t row_window_wide(uint64_t ext, int c0, int V) {
+    const int n = -c0;
+    const uint64_t right = (ext >> (c0 & 63)) | ((c0 > 0) ? (~0ull << ((64 - c0) & 63)) : 0ull);
+    const uint64_t left = (ext << (n & 63)) | ((1ull << (n & 63)) - 1ull);
+    const uint64_t w = (c0 >= 0) ? right : left;
     return (uint32_t)w & ((1u << V) - 1u);
 }
 
@@ -351,10 +397,20 @@ struct Lane {
 // `rec` must be readable for every lane (callers clamp the index of idle lanes to a real record): the three
 // 16-byte loads are unconditional, so they issue back to back with the wave's other loads instead of sitting in
 // an exec-masked branch with its own wait; idle lanes then replace what they read by the sentinels.
-__device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
+// Two halves so that a kernel can put other work (issuing more loads, waiting for scalar loads) between the
+// issue and the first use.
+struct LaneRaw {
+    uint4 q0, q1, q2;
+};
+__device__ __forceinline__ void lane_issue(const AgentRec *rec, LaneRaw &r) {
     const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
-    const uint4 q0 = rp[0], q1 = rp[1], q2 = rp[2];
-    st.dist = is_agent ? q2 : make_uint4(0, 0, 0, 0);
+    r.q0 = rp[0];
+    r.q1 = rp[1];
+    r.q2 = rp[2];
+}
+__device__ __forceinline__ void lane_unpack(const LaneRaw &r, bool is_agent, Lane &st) {
+    const uint4 q0 = r.q0, q1 = r.q1;
+    st.dist = is_agent ? r.q2 : make_uint4(0, 0, 0, 0);
     st.pos = is_agent ? (q0.x & 0xFFFFu) : (uint32_t)kIdleCell;
     st.goal = is_agent ? (q0.x >> 16) : (uint32_t)kIdleGoal;
     st.start = is_agent ? (q0.y & 0xFFFFu) : (uint32_t)kIdleCell;
@@ -362,6 +418,11 @@ __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, La
     st.moved = is_agent ? ((uint64_t)q0.z | ((uint64_t)q0.w << 32)) : 0ull;
     st.failed = is_agent ? ((uint64_t)q1.x | ((uint64_t)q1.y << 32)) : 0ull;
     st.progress = is_agent ? ((uint64_t)q1.z | ((uint64_t)q1.w << 32)) : 0ull;
+}
+__device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
+    LaneRaw r;
+    lane_issue(rec, r);
+    lane_unpack(r, is_agent, st);
 }
 
 // 16-byte state store; MAPF_STATE_STORE: 0 = plain (line stays in L2), 2 = sc1 write-through
@@ -575,10 +636,14 @@ struct PairOut {
     int coincide;   // other agents sharing my cell (0 by invariant)
 };
 
-template <class K, int LPE, int MW, bool FULL, bool USE_MAP = false>
+// MODE: kObsEmit = observation only (reset / observe kernels, and the observation wave of a step),
+//       kObsBoth = observation + pair outputs in one walk, kObsPairs = pair outputs only (the state wave of a step).
+constexpr int kObsEmit = 0, kObsBoth = 1, kObsPairs = 2;
+template <class K, int LPE, int MW, int MODE, bool USE_MAP = false>
 __device__ __forceinline__ void observe(const Params &p, const Io &io, const uint64_t *lrows, const uint4 *tabg, float *srow,
                                         bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
                                         bool pressure, int my_delta, PairOut &po, const uint32_t *map = nullptr) {
+    constexpr bool FULL = MODE != kObsEmit, EMIT = MODE != kObsPairs;
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
     constexpr int C = LPE < 8 ? LPE : 8;
     const int N = K::N(p), V = K::V(p), sr = K::sr(p);
@@ -593,8 +658,10 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     // lrows points at the env's row 0; kRowPad sentinel rows sit on either side, so no bounds checks
     uint64_t rows[MAXV];
     const int rbase = is_agent ? r0 : 0;
+    if (EMIT) {
 #pragma unroll
-    for (int d = 0; d < MAXV; d++) rows[d] = (d < V) ? lrows[rbase + d] : ~0ull;
+        for (int d = 0; d < MAXV; d++) rows[d] = (d < V) ? lrows[rbase + d] : ~0ull;
+    }
 
     uint32_t nbr_lo = 0, nbr_hi = 0;
     int sum_biased = 0, same_cell = 0;
@@ -609,7 +676,7 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
         const uint32_t new_lim1 = final_state ? 127u : me1 - 1u;
         const uint32_t old_lim = final_state ? 127u : me1;
         const uint32_t *win = map + (is_agent ? (r0 + kRowPad) * map_w + (c0 + kRowPad) : 0);
-        for (int d = 0; d < V; d++) {
+        for (int d = 0; EMIT && d < V; d++) {
             uint32_t wrow[MAXV];  // one window row per round trip: the V reads are issued back to back
 #pragma unroll
             for (int e = 0; e < MAXV; e++) wrow[e] = (e < V) ? win[d * map_w + e] : 0u;
@@ -665,12 +732,14 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
             const int j = j0 + u;
             const uint32_t Aj = e[u].x, Bj = e[u].y;
             const uint32_t newj = Aj >> 16;
-            const uint32_t pj = (final_state || j <= a) ? newj : (Aj & 0xFFFFu);
-            // occupancy (self included: it sets the centre bit, cleared below) and goals (own included)
-            const int pr = (int)(pj >> 8) - r0, pc = (int)(pj & 255u) - c0;
-            agm.set_if(max((unsigned)pr, (unsigned)pc) < (unsigned)V, __mul24(pr, V) + pc);
-            const int gr = (int)((Bj >> 8) & 255u) - r0, gc = (int)(Bj & 255u) - c0;
-            goals.set_if(max((unsigned)gr, (unsigned)gc) < (unsigned)V, __mul24(gr, V) + gc);
+            if (EMIT) {
+                const uint32_t pj = (final_state || j <= a) ? newj : (Aj & 0xFFFFu);
+                // occupancy (self included: it sets the centre bit, cleared below) and goals (own included)
+                const int pr = (int)(pj >> 8) - r0, pc = (int)(pj & 255u) - c0;
+                agm.set_if(max((unsigned)pr, (unsigned)pc) < (unsigned)V, __mul24(pr, V) + pc);
+                const int gr = (int)((Bj >> 8) & 255u) - r0, gc = (int)(Bj & 255u) - c0;
+                goals.set_if(max((unsigned)gr, (unsigned)gc) < (unsigned)V, __mul24(gr, V) + gc);
+            }
             if (FULL) {
                 const int d = cell_l1(newj, cur);
                 const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);  // 0 < d <= nearby
@@ -688,11 +757,18 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
         po.blocks = blocks;
         po.coincide = same_cell - 1;  // the loop counted me as well
     }
-    if (!is_agent) return;
+    if (!EMIT || !is_agent) return;
 
+    if (io.col_pad) {  // one wave-uniform branch around the whole window, not one per row
 #pragma unroll
-    for (int d = 0; d < MAXV; d++) {
-        if (d < V) obst.or_row(row_window(rows[d], c0, V, io.col_pad), d * V);
+        for (int d = 0; d < MAXV; d++) {
+            if (d < V) obst.or_row(row_window_padded(rows[d], c0, V, io.col_pad), d * V);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < MAXV; d++) {
+            if (d < V) obst.or_row(row_window_wide(rows[d], c0, V), d * V);
+        }
     }
     const int ctr = sr * V + sr;
     agm.clear_bit(ctr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
@@ -948,7 +1024,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         tabg[a] = static_entry(st.pos, st.goal);
         wave_lds_sync();
         PairOut po;
-        observe<K, LPE, MW, false>(p, io, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, stage + (size_t)(grp * N + a) * K::L(p),
+        observe<K, LPE, MW, kObsEmit>(p, io, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, stage + (size_t)(grp * N + a) * K::L(p),
                                    is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
         wave_lds_sync();
     }
@@ -967,6 +1043,8 @@ __device__ __forceinline__ void clear_cell_maps(const Io &io, uint32_t *map, int
 struct Lds {
     uint64_t *rows;
     uint4 *tab;
+    uint4 *otab;  // two-wave step kernels: the entries the observation wave reads (x old|new<<16, y goal, w kObsW*);
+                  // two copies, used alternately by consecutive steps of the fused kernel (carve_lds + set_parity)
     float *stage;
     int16_t *scratch;
     uint32_t *map;  // [G][H + 2*kRowPad][W + 2*kRowPad] cell words (only when Io::use_map)
@@ -975,6 +1053,7 @@ __device__ __forceinline__ Lds carve_lds(const Io &io, unsigned char *raw) {
     Lds l;
     l.rows = reinterpret_cast<uint64_t *>(raw);
     l.tab = reinterpret_cast<uint4 *>(raw + io.lds_tab_off);
+    l.otab = l.tab + 64;
     l.stage = reinterpret_cast<float *>(raw + io.lds_stage_off);
     l.scratch = reinterpret_cast<int16_t *>(raw + io.lds_scratch_off);
     l.map = reinterpret_cast<uint32_t *>(raw + io.lds_map_off);
@@ -1040,7 +1119,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
     PairOut po;
-    observe<K, LPE, MW, false>(p, io, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
+    observe<K, LPE, MW, kObsEmit>(p, io, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, l.stage + (size_t)(grp * N + a) * K::L(p), is_agent, a,
                                st.pos, st.goal, true, (st.flags & kFlagPressure) != 0, 0, po);
     wave_lds_sync();
     flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, env_ok ? 0 : 2);
@@ -1052,7 +1131,25 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // FAST = the wave is full (every group is a live env, every lane an agent) and no lane carries an invalid
 // action: every validity predicate below is then a compile-time constant and the error bookkeeping vanishes.
 // The general body handles ragged batches, N < LPE and the reference's mid-loop ValueError.
-template <class K, int LPE, int MW, bool FAST>
+//
+// DUAL = the workgroup has a second wave, the observation wave (obs_wave_step below): this function is then the
+// state wave.  It publishes what the observation needs in the pair table (entry word w, kObsW*), releases the
+// observation wave with a workgroup barrier and carries on with the lock detector, the per-step outputs and the
+// state image while the other wave builds, stages and streams out the observations.  With one wave per SIMD
+// (c3: 1024 workgroups on 1024 SIMDs) a step is bound by one wave's dependent-instruction latency, not by
+// bandwidth or issue slots; the split takes the observation (about a third of the instructions) off that path.
+constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSelShift = 3u, kObsWFast = 32u,
+                   kObsWReset = 64u;
+// LDS hand-off between the two waves of a workgroup.  Not __syncthreads(): that also waits for the wave's global
+// stores (vmcnt(0)), i.e. for the write-through observation stream to reach memory, once per barrier.  Only LDS
+// contents are exchanged here, so the wave waits for its own DS operations and then joins the barrier.
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class K, int LPE, int MW, bool FAST, bool DUAL>
 __device__ __forceinline__ void step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
                                           const int ngroups, int act, Lane &st, int *sc) {
     constexpr int G = 64 / LPE;
@@ -1120,6 +1217,36 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     bool grs = false;                      // goal_reached_step flag
     bool on_goal = live && cur == st.goal;  // reached_goal[i], evaluated at agent i's own turn
     bool reassigned = false;                // group-uniform: any lifelong respawn this step
+    // termination (MA-env:668-690) only needs on_goal and the step counter, so it is decided right after the move:
+    // the observation can then be built (and its stores leave) while the rest of the step is still being computed.
+    // Success check precedes the step-limit check.  (Lifelong never terminates on goals and resets on_goal below.)
+    int term = 0, trunc = 0;
+    float term_reward = 0.0f;
+    {
+        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+        if (!lifelong && n_on_goal == N) {
+            term_reward = 1.0f;
+            term = 1;
+        } else if (sc[MAPF_CTR_STEP_COUNT] >= io.steps_per_episode) {
+            if (!lifelong && !on_goal) term_reward = -1.0f;
+            term = 1;
+            trunc = 1;
+        }
+    }
+    const bool done = env_ok && !errored && (term | trunc);
+    const bool do_reset = done && io.auto_reset;
+    // which tensor a group's observation goes to: 0 io.obs, 1 io.final_obs (terminal observation of an env that is
+    // reset right away), 2 nowhere
+    const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
+    const bool obs_wave = DUAL && (io.obs || io.final_obs);  // the other wave works this step (workgroup-uniform)
+    uint4 *otabg = l.otab + grp * LPE;
+    const uint32_t obs_w0 = (is_agent ? kObsWAgent : 0u) | (pressure_prev ? kObsWPressure : 0u) |
+                            ((uint32_t)sel << kObsWSelShift) | (FAST ? kObsWFast : 0u) | (do_reset ? kObsWReset : 0u);
+    if (obs_wave && !lifelong) {  // finite episodes: goals are fixed, the observation only waited for the moves
+        otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0);
+        wg_sync();  // B1
+    }
+
     if (!lifelong) {
         if (on_goal && !reached) {
             reached = true;
@@ -1234,32 +1361,20 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         sc[MAPF_CTR_HIST_ROWS] = t + 1;
     }
 
-    // termination (MA-env:668-690) only needs on_goal and the step counter, so it is decided BEFORE the pair
-    // pass: the observation stores can then leave right after the emit and drain under the rest of the step.
-    // Success check precedes the step-limit check.
-    int term = 0, trunc = 0;
-    float term_reward = 0.0f;
-    {
-        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
-        if (!lifelong && n_on_goal == N) {
-            term_reward = 1.0f;
-            term = 1;
-        } else if (sc[MAPF_CTR_STEP_COUNT] >= io.steps_per_episode) {
-            if (!lifelong && !on_goal) term_reward = -1.0f;
-            term = 1;
-            trunc = 1;
-        }
-    }
-    const bool done = env_ok && !errored && (term | trunc);
-    const bool do_reset = done && io.auto_reset;
-
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
     PairOut po;
     float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
+    // this wave builds the observation itself unless the other wave does, or nobody asked for one (fused steps
+    // without observations)
+    const bool emit_here = !obs_wave && (io.obs || io.final_obs);
+    if (obs_wave && lifelong) {  // respawned goals are part of the observation: publish after the goal logic
+        otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (reassigned ? kObsWFinal : 0u));
+        wg_sync();  // B1
+    }
     if (use_map) {
         // large N: every agent ORs its remaining fields into the env's cell map (owner-old went in before the move),
-        // then reads only its window and lock neighbourhood from it
+        // then reads only its window and lock neighbourhood from it (single-wave workgroups only: dual_for())
         if (is_agent) {
             const uint32_t me1 = (uint32_t)a + 1u;
             atomicOr(&mapg[map_index(cur, map_w)], me1 | ((uint32_t)(delta + 256) << 22));
@@ -1269,8 +1384,12 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         }
         wave_lds_sync();
         MAPF_STAMP(3);
-        observe<K, LPE, MW, true, MAP_OK>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned, pressure_prev,
-                                          delta, po, mapg);
+        if (emit_here)
+            observe<K, LPE, MW, kObsBoth, MAP_OK>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned,
+                                                  pressure_prev, delta, po, mapg);
+        else
+            observe<K, LPE, MW, kObsPairs, MAP_OK>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned,
+                                                   pressure_prev, delta, po, mapg);
     } else {
         uint4 ent;
         ent.x = old | (cur << 16);
@@ -1280,18 +1399,24 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         tabg[a] = ent;
         wave_lds_sync();
         MAPF_STAMP(3);
-        observe<K, LPE, MW, true, false>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned, pressure_prev,
-                                         delta, po);
+        if (emit_here)
+            observe<K, LPE, MW, kObsBoth, false>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned,
+                                                 pressure_prev, delta, po);
+        else
+            observe<K, LPE, MW, kObsPairs, false>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned,
+                                                  pressure_prev, delta, po);
     }
     MAPF_STAMP(4);
 
-    // ---- observations leave the wave as one contiguous stream ------------------------------------
-    wave_lds_sync();
-    if (FAST && !__any(do_reset)) {
-        if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
-    } else if (io.obs || io.final_obs) {
-        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
+    // ---- observations leave the wave as one contiguous stream (single-wave mode; otherwise the observation
+    //      wave does this, concurrently with everything below) --------------------------------------------
+    if (emit_here) {
+        wave_lds_sync();
+        if (FAST && !__any(do_reset)) {
+            if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
+        } else {
+            flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
+        }
     }
     MAPF_STAMP(5);
 
@@ -1408,51 +1533,134 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     //      reset() right after a done step) ------------------------------------------------------------
     if (__any(do_reset)) {
         if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
-        wave_lds_sync();
+        if (obs_wave) wg_sync();  // B2: the observation wave is done with the table and the staging rows
+        else wave_lds_sync();
         reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
                                  sc, io.obs != nullptr);
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }
 }
 
+// The fused kernel alternates between the two copies of the observation table, so that the state wave may publish
+// step t+1 while the observation wave still reads step t (no end-of-step barrier).
+__device__ __forceinline__ Lds with_parity(const Lds &l, int t) {
+    Lds r = l;
+    r.otab = l.otab + (t & 1) * 64;
+    return r;
+}
+
+// One step of the observation wave (wave 1 of a DUAL workgroup).  Everything it needs arrives through LDS: the
+// obstacle rows and the observation table Lds::otab (its own entry carries cur / goal / kObsW* flags).  Barrier protocol per step with observations, identical in both waves: B1 (table complete), then B2
+// only if some env of the workgroup resets (the state wave re-uses table and staging rows for the reset).
 template <class K, int LPE, int MW>
-__global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, const Io io) {
+__device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
+                                              const int ngroups) {
+    const int grp = lane / LPE, a = lane % LPE;
+    const int N = K::N(p), H = io.H;
+    const uint4 *otabg = l.otab + grp * LPE;
+    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
+    float *srow = l.stage + (size_t)(grp * N + min(a, N - 1)) * K::L(p);
+    wg_sync();  // B1
+    MAPF_STAMP_W1(11);
+    const uint4 ent = otabg[a];
+    const uint32_t w = ent.w;
+    const bool is_agent = (w & kObsWAgent) != 0;
+    PairOut po;
+    observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
+                                         (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po);
+    wave_lds_sync();
+    MAPF_STAMP_W1(12);
+    const bool any_reset = __any((w & kObsWReset) != 0);
+    if (__all((w & kObsWFast) != 0) && !any_reset) {
+        if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
+    } else {
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, (int)((w >> kObsWSelShift) & 3u));
+    }
+    MAPF_STAMP_W1(13);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MAPF_STAMP_W1(14);
+#endif
+    if (any_reset) wg_sync();  // B2
+}
+
+// Workgroup shape of the step kernels: kStepWaves waves of 64 lanes.  Wave 0 is the state wave, wave 1 (when
+// present) the observation wave.  MAPF_DUAL=0 builds the single-wave variant (A/B measurements).
+#ifndef MAPF_DUAL
+#define MAPF_DUAL 1
+#endif
+// Wide groups (N > 16: the LDS cell-map path) stay single-wave: there the map atomics and the extra barrier
+// cost more than the split saves (measured on c5).
+constexpr bool dual_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
+constexpr int step_threads(int lpe) { return dual_for(lpe) ? 128 : 64; }
+
+template <class K, int LPE, int MW>
+__global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+                                                            const IoTail tail) {
+    MAPF_STAMP_ENTRY();
     const Params &p = *pp;
-    warm_scalar_cache(pp, io);
+    const Io io = MAPF_IO_JOIN;
     constexpr int G = 64 / LPE;
+    constexpr bool kDual = dual_for(LPE);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const Lds l = carve_lds(io, lds_raw);
-    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int wv = kDual ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G;
     const int ngroups = min(G, io.B - env0);
     const int N = K::N(p);
+
+    // Both waves issue their global loads from the preloaded arguments alone, and only then wait for the scalar
+    // loads (rest of the arguments, Params) in one batch.
+    if (kDual && wv == 1) {
+        // ---- observation wave: fetches the obstacle rows for both waves, then builds and streams the observations
+        RowRegs rr;
+        rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+        __builtin_amdgcn_sched_barrier(0);
+        warm_scalar_cache(pp, tail);
+        const Lds l = carve_lds(io, lds_raw);
+        rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
+        wg_sync();  // B0: rows visible to the state wave
+        MAPF_STAMP_W1(10);
+        if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+        return;
+    }
+
     const bool full = ngroups == G && N == LPE;  // wave-uniform
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
 
-    MAPF_STAMP(0);
-    // ---- loads: agent record, action, env scalars, obstacle rows; every load is issued before the first wait
-    Lane st;
-    RowRegs rr;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
+    // ---- loads: agent record, action, env scalars (and the obstacle rows in the single-wave build)
+    LaneRaw raw;
+    lane_issue(io.agents + (size_t)env * N + min(a, N - 1), raw);
     int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
-    act = (full || is_agent) ? act : 0;
     int sc[12];
     load_scal(io.scal, env, sc);
-    rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
-    __builtin_amdgcn_sched_barrier(0);  // keep the LDS work below from being hoisted between the loads
-    if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
-    rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
-    wave_lds_sync();
+    RowRegs rr;
+    if (!kDual) rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+    __builtin_amdgcn_sched_barrier(0);  // nothing below may be hoisted between the loads
+    warm_scalar_cache(pp, tail);
+    __builtin_amdgcn_sched_barrier(0);
+    const Lds l = carve_lds(io, lds_raw);
+    Lane st;
+    lane_unpack(raw, full || is_agent, st);
+    act = (full || is_agent) ? act : 0;
+    MAPF_STAMP(0);
+    if (kDual) {
+        wg_sync();  // B0
+    } else {
+        if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
+        rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
+        wave_lds_sync();
+    }
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
 #endif
     MAPF_STAMP(1);
     if (full && !__any(act < 0 || act > 4))
-        step_body<K, LPE, MW, true>(p, io, l, lane, env0, ngroups, act, st, sc);
+        step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
     else
-        step_body<K, LPE, MW, false>(p, io, l, lane, env0, ngroups, act, st, sc);
+        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
     if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);
     MAPF_STAMP(8);
@@ -1460,6 +1668,7 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain
 #endif
     MAPF_STAMP(9);
+    MAPF_STAMP_ENTRY_STORE();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1467,19 +1676,45 @@ __global__ __launch_bounds__(64) void k_step(const Params *__restrict__ pp, cons
 // per-step action bytes are read and the per-step outputs written.  actions [T][B][N]; every non-null
 // output is [T][...] except obs: obs_mode 0 = none, 1 = observation after the last step only, 2 = every step.
 // Finished envs are reset inside the loop (auto_reset semantics of mapf_step).
+// Two-wave workgroups: on every step that produces observations the waves meet at B1 (observation table
+// published) and at B2 if an env resets.  There is no end-of-step barrier: the observation table is double
+// buffered, the staging rows belong to the observation wave (the state wave touches them only between B2 and the
+// next B1), so the state wave runs up to one step ahead and the two waves overlap across step boundaries.
 // ------------------------------------------------------------------------------------------------
 template <class K, int LPE, int MW>
-__global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp, const Io io, const int T,
-                                                  const int obs_mode) {
+__global__ __launch_bounds__(step_threads(LPE)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+                                                                 const IoTail tail, const int T, const int obs_mode) {
     const Params &p = *pp;
-    warm_scalar_cache(pp, io);
+    warm_scalar_cache(pp, tail);
+    const Io io = MAPF_IO_JOIN;
     constexpr int G = 64 / LPE;
+    constexpr bool kDual = dual_for(LPE);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds l = carve_lds(io, lds_raw);
-    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int wv = kDual ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G;
     const int ngroups = min(G, io.B - env0);
     const int N = K::N(p), L = K::L(p);
+    const size_t BN = (size_t)io.B * N;
+    // the observation tensor of step t (nullptr: this step produces none)
+    auto obs_of = [&](int t) -> float * {
+        return obs_mode == 2 ? io.obs + (size_t)t * BN * L : ((obs_mode == 1 && t == T - 1) ? io.obs : nullptr);
+    };
+
+    if (kDual && wv == 1) {
+        load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+        wg_sync();  // B0
+        for (int t = 0; t < T; t++) {
+            Io it = io;
+            it.final_obs = nullptr;
+            it.obs = obs_of(t);
+            if (it.obs == nullptr) continue;
+            obs_wave_step<K, LPE, MW>(p, it, with_parity(l, t), lane, env0, ngroups);
+        }
+        return;
+    }
+
     const bool full = ngroups == G && N == LPE;
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
@@ -1489,10 +1724,13 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
     load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
-    load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
-    wave_lds_sync();
+    if (kDual) {
+        wg_sync();  // B0
+    } else {
+        load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
+        wave_lds_sync();
+    }
 
-    const size_t BN = (size_t)io.B * N;
     for (int t = 0; t < T; t++) {
         if (LPE >= 32 && io.use_map) {
             clear_cell_maps<LPE>(io, l.map, lane);
@@ -1501,18 +1739,19 @@ __global__ __launch_bounds__(64) void k_step_many(const Params *__restrict__ pp,
         Io it = io;
         it.auto_reset = 1;
         it.final_obs = nullptr;
-        it.obs = obs_mode == 2 ? io.obs + (size_t)t * BN * L : ((obs_mode == 1 && t == T - 1) ? io.obs : nullptr);
+        it.obs = obs_of(t);
         if (io.rewards) it.rewards = io.rewards + (size_t)t * BN;
         if (io.terminated) it.terminated = io.terminated + (size_t)t * io.B;
         if (io.truncated) it.truncated = io.truncated + (size_t)t * io.B;
         if (io.info_all) it.info_all = io.info_all + (size_t)t * io.B * MAPF_INFO_ALL;
         if (io.info_agent) it.info_agent = io.info_agent + (size_t)t * BN * 2;
-        int act = (full || is_agent) ? (int)io.actions[(size_t)t * BN + (size_t)env * N + a] : 0;
+        int act = (int)io.actions[(size_t)t * BN + (size_t)env * N + min(a, N - 1)];
+        act = (full || is_agent) ? act : 0;
         if (full && !__any(act < 0 || act > 4))
-            step_body<K, LPE, MW, true>(p, it, l, lane, env0, ngroups, act, st, sc);
+            step_body<K, LPE, MW, true, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
         else
-            step_body<K, LPE, MW, false>(p, it, l, lane, env0, ngroups, act, st, sc);
-        wave_lds_sync();  // staging / table regions are reused by the next step
+            step_body<K, LPE, MW, false, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
+        wave_lds_sync();  // this wave's staging / table regions are reused by the next step
     }
     if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);

@@ -99,10 +99,15 @@ int pick_lpe(int n) {
 
 enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 
+// the step kernels take the head of Io as individual (preloadable) arguments
+#define IO_HEAD_ARGS(io) (io).agents, (io).scal, (io).grid_rows, (io).actions, (io).B, (io).H, (io).W, (io).col_pad, \
+                         static_cast<const IoTail &>(io)
+
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP)
-        hipLaunchKernelGGL((k_step<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+        hipLaunchKernelGGL((k_step<KRuntime, LPE, MW>), dim3(e->blocks), dim3(step_threads(LPE)), e->lds_bytes, s, e->d_params,
+                           IO_HEAD_ARGS(io));
     else if (kind == KIND_RESET)
         hipLaunchKernelGGL((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     else
@@ -129,7 +134,7 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
         hipLaunchKernelGGL((k_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),        \
-                           dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);                            \
+                           dim3(e->blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io)); \
         return hipGetLastError();
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
@@ -139,7 +144,7 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 
 template <int LPE, int MW>
 hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
-    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io, T,
+    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(step_threads(LPE)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,
                        obs_mode);
     return hipGetLastError();
 }
@@ -149,7 +154,8 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
         hipLaunchKernelGGL((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),   \
-                           dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io, T, obs_mode);               \
+                           dim3(e->blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
+                           obs_mode);                                                                               \
         return hipGetLastError();
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
@@ -283,7 +289,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.scratch_i16 = (p.hash_cap + 2 * N + 1) & ~1;
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * (H + 2 * kRowPad) * 8) + 15) & ~15;  // kRowPad sentinel rows on either side
-    const int tab_bytes = 64 * 16;  // one 16-byte entry per lane
+    const int tab_bytes = 3 * 64 * 16;  // one 16-byte entry per lane: pair table + two observation-wave tables
     const int stage_bytes = ((G * (cte ? (H * W + 5 * N) : N * p.L) * 4) + 15) & ~15;
     const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
     p.lds_tab_off = rows_bytes;
@@ -818,7 +824,7 @@ int mapf_debug_stamps(mapf_handle e, uint64_t *out, int32_t max_words) {
 int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env) {
     if (!e) return MAPF_ERR_CONFIG;
     if (blocks) *blocks = e->blocks;
-    if (threads) *threads = 64;
+    if (threads) *threads = step_threads(e->lpe);  /* step kernels: state wave + observation wave */
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (lanes_per_env) *lanes_per_env = e->lpe;
     return e->special;  /* >= 0: id of the compile-time specialisation in use (0 = runtime-config kernel) */

@@ -33,8 +33,9 @@ for t in range(20):
     buf = np.zeros(blocks * 16, dtype=np.uint64)
     n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
     assert n == buf.size, n
-    rows.append(buf.reshape(blocks, 16)[:, :10].astype(np.int64))
-st = np.stack(rows)  # [T, blocks, 10]
+    rows.append(buf.reshape(blocks, 16).astype(np.int64))
+full = np.stack(rows)  # [T, blocks, 16]
+st = full[:, :, :10]
 d = np.diff(st, axis=2)
 names = ["loads+sync", "move", "goal/lock/term/table", "pair loop+emit", "flush obs", "lock detector", "outputs",
          "state stores", "drain stores"]
@@ -46,3 +47,15 @@ print(f"  {'wave total':22s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f
 start = st[:, :, 0] - st[:, :, 0].min(axis=1, keepdims=True)
 end = st[:, :, 9] - st[:, :, 0].min(axis=1, keepdims=True)
 print(f"  first->last wave start spread: median {np.median(start.max(axis=1)):.0f}; kernel span (first start -> last end) median {np.median(end.max(axis=1)):.0f}")
+if env.launch_info()["threads"] == 128:  # observation wave, relative to the state wave's first stamp
+    w1 = full[:, :, 10:15] - st[:, :, 0:1]
+    for k, nme in enumerate(["obs wave: rows loaded (B0)", "obs wave: released (B1)", "obs wave: observation staged",
+                             "obs wave: stores issued", "obs wave: stores drained"]):
+        print(f"  {nme:30s} at median {np.median(w1[:, :, k]):9.0f}  p95 {np.percentile(w1[:, :, k], 95):9.0f}")
+    cum = st - st[:, :, 0:1]
+    print("  state wave stamps at median " + " ".join(f"{np.median(cum[:, :, k]):.0f}" for k in range(10)))
+pre = st[:, :, 0] - full[:, :, 15]
+print(f"  wave entry -> first stamp (scalar loads: kernel arguments + Params): median {np.median(pre):.0f}  p95 {np.percentile(pre, 95):.0f}")
+ent = full[:, :, 15] - full[:, :, 15].min(axis=1, keepdims=True)
+endw = st[:, :, 9] - full[:, :, 15].min(axis=1, keepdims=True)
+print(f"  wave entry spread over the grid: median {np.median(ent):.0f}  p95 {np.percentile(ent, 95):.0f}  max {np.median(ent.max(axis=1)):.0f};  first entry -> last state-wave end: {np.median(endw.max(axis=1)):.0f}")
