@@ -874,8 +874,8 @@ __device__ __forceinline__ void flush_obs_full(const Params &p, const Io &io, fl
     const int n = G * NL;
     float *dst = flat + (size_t)env0 * NL;
     if ((n & 3) == 0) {
-        const ObsSink sink = make_obs_sink(flat, (unsigned)io.B * (unsigned)NL * 4u);
-        const unsigned off0 = (unsigned)env0 * (unsigned)NL * 4u + (unsigned)lane * 16u;
+        const ObsSink sink = make_obs_sink(dst, (unsigned)n * 4u);  // wave-relative: offsets stay small
+        const unsigned off0 = (unsigned)lane * 16u;
         const int n4 = n >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(stage);
         if (K::kFixed) {
@@ -920,7 +920,9 @@ __device__ __forceinline__ void flush_rows(const Io &io, const float *stage, int
         if (((G * NL) & 3) == 0) {
             const int n4 = n >> 2;
             const float4 *s4 = reinterpret_cast<const float4 *>(stage);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            // write-through stream like flush_obs_full; the sink is addressed from the wave's own first byte so that
+            // the 32-bit buffer offsets stay small whatever the size of the tensor
+            const ObsSink sink = make_obs_sink(dst, (unsigned)n * 4u);
             // rounds of 4 x 1 KiB: the four LDS reads are issued back to back, then the four stores
             for (int k0 = 0; k0 < n4; k0 += 256) {
                 // unconditional (clamped) reads keep v[] in registers; only the stores are predicated
@@ -928,10 +930,11 @@ __device__ __forceinline__ void flush_rows(const Io &io, const float *stage, int
                 const float4 v1 = s4[min(k0 + 64 + lane, n4 - 1)];
                 const float4 v2 = s4[min(k0 + 128 + lane, n4 - 1)];
                 const float4 v3 = s4[min(k0 + 192 + lane, n4 - 1)];
-                if (k0 + lane < n4) d4[k0 + lane] = v0;
-                if (k0 + 64 + lane < n4) d4[k0 + 64 + lane] = v1;
-                if (k0 + 128 + lane < n4) d4[k0 + 128 + lane] = v2;
-                if (k0 + 192 + lane < n4) d4[k0 + 192 + lane] = v3;
+                const unsigned off = (unsigned)(k0 + lane) * 16u;
+                if (k0 + lane < n4) store_obs4(sink, off, v0);
+                if (k0 + 64 + lane < n4) store_obs4(sink, off + 1024u, v1);
+                if (k0 + 128 + lane < n4) store_obs4(sink, off + 2048u, v2);
+                if (k0 + 192 + lane < n4) store_obs4(sink, off + 3072u, v3);
             }
             for (int k = (n4 << 2) + lane; k < n; k += 64) dst[k] = stage[k];
         } else {
@@ -1789,9 +1792,33 @@ __device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const 
                                             bool env_ok, bool is_agent, int a, uint32_t pos, uint32_t goal) {
     const int H = io.H, W = io.W, HW = H * W;
     if (env_ok) {
-        for (int r = 0; r < H; r++) {
-            const uint64_t bits = lrows[r] >> io.col_pad;
-            for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
+        if ((W & 3) == 0) {
+            // four cells per lane and round: the lanes of the group take consecutive 4-cell chunks of the row-major
+            // grid; (row, chunk) advance incrementally, so there is no division in the loop
+            const int cpr = W >> 2;                     // chunks per row
+            const int dq_r = LPE / cpr, dq_c = LPE - dq_r * cpr;
+            int r = a / cpr, c = a - r * cpr;
+            constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
+            for (int q = a; q < H * cpr; q += LPE) {
+                const uint32_t nib = (uint32_t)(lrows[r] >> (io.col_pad + 4 * c)) & 15u;
+                const uint32_t by = (nib * KS) & MS;
+                float *d = srow + r * W + 4 * c;
+                d[0] = (float)(by & 0xFFu);
+                d[1] = (float)((by >> 8) & 0xFFu);
+                d[2] = (float)((by >> 16) & 0xFFu);
+                d[3] = (float)(by >> 24);
+                r += dq_r;
+                c += dq_c;
+                if (c >= cpr) {
+                    c -= cpr;
+                    r++;
+                }
+            }
+        } else {
+            for (int r = 0; r < H; r++) {
+                const uint64_t bits = lrows[r] >> io.col_pad;
+                for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
+            }
         }
     }
     wave_lds_sync();

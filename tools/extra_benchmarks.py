@@ -71,7 +71,47 @@ def run(name, over=None, fused_T=100, p=None, tag=None):
     print(json.dumps(out), flush=True)
 
 
+def run_cte(b=8192, h=16, w=16, n=4, density=0.20, lanes=0):
+    """Single-agent (CTE) sibling env: full-grid observation (H*W + 5N floats per env), one launch per step."""
+    from dl_reference_models_amd.vec_env_single_agent import VecSingleAgentReferenceModel
+    grids = wl.synthetic_grids(list(range(b)), h, w, density, n)
+    env = VecSingleAgentReferenceModel({"num_envs": b, "num_agents": n, "grid": grids, "seeds": list(range(b)),
+                                        "steps_per_episode": 100, "lanes_per_env": lanes})
+    env.reset()
+    pool = 100
+    acts = torch.from_numpy(np.random.default_rng(999).integers(0, 5, size=(pool, b, n)).astype(np.int8)).to(env.device)
+
+    def steps():
+        for t in range(pool):
+            env.step(acts[t], auto_reset=True)
+
+    steps()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        steps()
+    for _ in range(3):
+        g.replay()
+    dt = timed(g.replay, 10)
+    us = 1e6 * dt / (pool * 10)
+    # algorithmic bytes per env-step: observation row written, agent records + env scalars read and written,
+    # obstacle rows and actions read, reward / flags / info written
+    bytes_env = 4 * env.obs_len + 2 * 48 * n + 2 * 64 + 8 * h + n + 8 + 2 + 16
+    env.poll_error()
+    print(json.dumps({"workload": f"CTE single-agent env {b} x {h}x{w} x {n} agents (obs {env.obs_len} floats/env)",
+                      "envs": b, "agents": n, "obs_floats": env.obs_len, "lanes_per_env": lanes,
+                      "single_step_per_launch": {"env_steps_per_s": b * pool * 10 / dt, "agent_steps_per_s": b * n * pool * 10 / dt,
+                                                 "us_per_step": us, "algorithmic_bytes_per_env_step": bytes_env,
+                                                 "roofline_frac": bytes_env * b / (us * 1e-6) / 8e12}}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cte":
+        for lanes in (0, 8, 16, 32, 64):
+            run_cte(lanes=lanes)
+        for lanes in (0, 16, 32, 64):
+            run_cte(b=1024, h=32, w=32, n=8, density=0.2, lanes=lanes)
+        sys.exit(0)
     run("c3_8192x32x32_n8")
     run("c3_8192x32x32_n8", {"include_action_mask_in_obs": False}, tag="c3 reference-default obs (mask off, L=28)")
     run("c3_8192x32x32_n8", p=[0.1, 0.1, 0.3, 0.4, 0.1], tag="c3 goal-biased action stream")
