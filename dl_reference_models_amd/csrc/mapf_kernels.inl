@@ -2,11 +2,13 @@
 //
 // "MA-env:N" = /root/reference/src/environments/reference_model_multi_agent.py line N.
 //
-// Execution shape: one 64-lane wavefront per workgroup.  An env owns a GROUP of LPE consecutive
-// lanes (LPE = power of two >= N); lane a of the group is agent a, so a wave steps 64/LPE envs
-// (N = 64: one wavefront per env; N = 8: eight envs per wave, no idle lanes in the agent phases).
-// A single wave per workgroup means every LDS hand-off below is intra-wave: LDS executes a wave's
-// DS instructions in order, so a compiler-level fence is all the synchronisation that is needed.
+// Execution shape: an env owns a GROUP of LPE consecutive lanes (LPE = power of two >= N); lane a of
+// the group is agent a, so a 64-lane wave steps 64/LPE envs (N = 64: one wavefront per env; N = 8: eight
+// envs per wave, no idle lanes in the agent phases).  The reset / observe / single-agent kernels run one
+// wave per workgroup; the step kernels add a second wave over the same agents for N <= 16 (state wave +
+// observation wave, see step_body / obs_wave_step).  Inside a wave every LDS hand-off is intra-wave: LDS
+// executes a wave's DS instructions in order, so a compiler-level fence is all the synchronisation that is
+// needed (wave_lds_sync); the two waves of a step workgroup meet at LDS-only barriers (wg_sync).
 //
 // Cross-lane traffic goes through two LDS tables per step (one entry per lane, written once, then
 // read by every lane of the group with 16-byte reads), instead of one broadcast per agent pair:
@@ -16,8 +18,9 @@
 // Lanes that hold no agent publish sentinel entries that fail every test, so the pair loops carry no
 // "is this a real agent" predicate.
 //
-// With one wave per SIMD the kernel is instruction-issue bound (measured: profiles/r01), so the env
-// configuration is a template policy: KFixed<...> turns agent count, sensor range, observation layout,
+// At the headline shape the launch is one or two waves per SIMD and a step is bound by the waves' chains of
+// dependent instructions (measured: profiles/r01), so the env configuration is a
+// template policy: KFixed<...> turns agent count, sensor range, observation layout,
 // flags and lock windows into compile-time constants for the BASELINE.json shapes, KRuntime keeps
 // every other configuration working from the same source.
 
@@ -251,7 +254,7 @@ __device__ __forceinline__ uint32_t gshfl(uint32_t v, int j) {
     return (uint32_t)__shfl((int)v, j, LPE);
 }
 
-// intra-wave LDS hand-off point (one wave per workgroup: DS ops of a wave execute in order)
+// intra-wave LDS hand-off point (DS ops of one wave execute in order)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -622,7 +625,7 @@ __device__ __forceinline__ uint32_t resolve_moves_map(const Params &p, uint32_t 
 
 // ------------------------------------------------------------------------------------------------
 // observation of every agent lane -> LDS staging row (MA-env:707-747 get_obs, :749-773 mask,
-// :306-335 flatten), fused with the other all-pairs work of a step when FULL: neighbour sets of
+// :306-335 flatten), fused with the other all-pairs work of a step (MODE below): neighbour sets of
 // the lock detector (MA-env:389-398), intent blocking (:608-623), coincidence penalty (:658-666).
 // Pair-table entry of agent j:
 //   x = old | new<<16      y = goal | reached<<16 | (delta+256)<<17      z = intended cell (+1,+1) or ~0
@@ -1245,7 +1248,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     uint4 *otabg = l.otab + grp * LPE;
     const uint32_t obs_w0 = (is_agent ? kObsWAgent : 0u) | (pressure_prev ? kObsWPressure : 0u) |
                             ((uint32_t)sel << kObsWSelShift) | (FAST ? kObsWFast : 0u) | (do_reset ? kObsWReset : 0u);
-    if (obs_wave && !lifelong) {  // finite episodes: goals are fixed, the observation only waited for the moves
+    if (obs_wave && !lifelong && !use_map) {  // finite episodes: goals are fixed, the observation only waited for the moves
         otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0);
         wg_sync();  // B1
     }
@@ -1371,7 +1374,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
     // this wave builds the observation itself unless the other wave does, or nobody asked for one (fused steps
     // without observations)
     const bool emit_here = !obs_wave && (io.obs || io.final_obs);
-    if (obs_wave && lifelong) {  // respawned goals are part of the observation: publish after the goal logic
+    if (obs_wave && lifelong && !use_map) {  // respawned goals are part of the observation: publish after the goal logic
         otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (reassigned ? kObsWFinal : 0u));
         wg_sync();  // B1
     }
@@ -1385,7 +1388,12 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
             // intended_next may lie one cell outside the grid: that is inside the map's border
             if (!reached) atomicOr(&mapg[(tr + kRowPad) * map_w + tc + kRowPad], 1u << 21);
         }
-        wave_lds_sync();
+        if (obs_wave) {  // the observation wave reads its window from the map: release it when the map is complete
+            otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (reassigned ? kObsWFinal : 0u));
+            wg_sync();  // B1
+        } else {
+            wave_lds_sync();
+        }
         MAPF_STAMP(3);
         if (emit_here)
             observe<K, LPE, MW, kObsBoth, MAP_OK>(p, io, myrows, tabg, srow, is_agent, a, cur, st.goal, reassigned,
@@ -1569,6 +1577,13 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
     const uint32_t w = ent.w;
     const bool is_agent = (w & kObsWAgent) != 0;
     PairOut po;
+    constexpr bool MAP_OK = LPE >= 32;
+    if (MAP_OK && io.use_map) {
+        const int map_w = io.W + 2 * kRowPad;
+        observe<K, LPE, MW, kObsEmit, MAP_OK>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
+                                              (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po,
+                                              l.map + grp * (H + 2 * kRowPad) * map_w);
+    } else
     observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
                                          (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po);
     wave_lds_sync();
@@ -1592,10 +1607,13 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
 #ifndef MAPF_DUAL
 #define MAPF_DUAL 1
 #endif
-// Wide groups (N > 16: the LDS cell-map path) stay single-wave: there the map atomics and the extra barrier
-// cost more than the split saves (measured on c5).
-constexpr bool dual_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
+// k_step uses the split for every group width (c5, N = 64 with the LDS cell map: 10.2 -> 8.8 us).  The fused
+// kernel keeps wide groups single-wave: its cell map is single-buffered, so the waves would have to meet at the
+// end of every step, and the loop body then spills several hundred SGPRs (measured: 5.9 -> 8.8 us per step).
+constexpr bool dual_for(int lpe) { return MAPF_DUAL != 0 && lpe >= 4; }
+constexpr bool dual_many_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
 constexpr int step_threads(int lpe) { return dual_for(lpe) ? 128 : 64; }
+constexpr int many_threads(int lpe) { return dual_many_for(lpe) ? 128 : 64; }
 
 template <class K, int LPE, int MW>
 __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
@@ -1621,6 +1639,7 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
+        if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wg_sync();  // B0: rows visible to the state wave
         MAPF_STAMP_W1(10);
@@ -1680,18 +1699,19 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
 // output is [T][...] except obs: obs_mode 0 = none, 1 = observation after the last step only, 2 = every step.
 // Finished envs are reset inside the loop (auto_reset semantics of mapf_step).
 // Two-wave workgroups: on every step that produces observations the waves meet at B1 (observation table
-// published) and at B2 if an env resets.  There is no end-of-step barrier: the observation table is double
-// buffered, the staging rows belong to the observation wave (the state wave touches them only between B2 and the
-// next B1), so the state wave runs up to one step ahead and the two waves overlap across step boundaries.
+// published) and at B2 if an env resets.  There is no end-of-step barrier on the pair-table path: the observation
+// table is double buffered, the staging rows belong to the observation wave (the state wave touches them only
+// between B2 and the next B1), so the state wave runs up to one step ahead and the two waves overlap across step
+// boundaries.  Wide groups (the single-buffered LDS cell map) run this kernel with one wave: dual_many_for().
 // ------------------------------------------------------------------------------------------------
 template <class K, int LPE, int MW>
-__global__ __launch_bounds__(step_threads(LPE)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+__global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
                                                                  const IoTail tail, const int T, const int obs_mode) {
     const Params &p = *pp;
     warm_scalar_cache(pp, tail);
     const Io io = MAPF_IO_JOIN;
     constexpr int G = 64 / LPE;
-    constexpr bool kDual = dual_for(LPE);
+    constexpr bool kDual = dual_many_for(LPE);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const Lds l = carve_lds(io, lds_raw);
     const int wv = kDual ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;

@@ -144,7 +144,7 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 
 template <int LPE, int MW>
 hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
-    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(step_threads(LPE)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,
+    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,
                        obs_mode);
     return hipGetLastError();
 }
@@ -154,7 +154,7 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
         hipLaunchKernelGGL((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),   \
-                           dim3(e->blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
+                           dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
                            obs_mode);                                                                               \
         return hipGetLastError();
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
