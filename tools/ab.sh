@@ -1,6 +1,5 @@
 #!/bin/bash
-# A/B several builds of the library in one GPU session: bash tools/ab.sh lib1.so lib2.so ...  (3 interleaved rounds)
-for r in 1 2 3; do for L in "$@"; do
-  MAPF_LIB=$L timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3000 --warmup 500 --kernel-samples 0 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$L round $r kernel_us %.3f value %.4g' % (1e3*d['roofline']['kernel_ms'], d['value']))"
-done; done
+# A/B of the headline bench over alternative builds: bash tools/ab.sh [lib ...]   (the shipped library runs first)
+run() { timeout -k 10 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('${MAPF_LIB:-shipped}', round(d['value']/1e9, 3), 'G', round(d['ms_per_step']*1e3, 3), 'us')"; }
+unset MAPF_LIB; run || exit 1
+for L in "$@"; do export MAPF_LIB=$L; run || exit 1; done

@@ -22,8 +22,10 @@ def timed(fn, n):
     return e0.elapsed_time(e1) * 1e-3
 
 
-def run(name, over=None, fused_T=100, p=None, tag=None):
+def run(name, over=None, fused_T=100, p=None, tag=None, envs=None):
     b, h, w, n, density, _ = wl.WORKLOADS[name]
+    if envs is not None:  # batch-size sweep: the same per-env workload, more envs on the one GPU
+        b = envs
     cfg = wl.workload_config(name, list(range(b)))
     cfg.update(over or {})
     env = VecReferenceModel(cfg)
@@ -106,6 +108,12 @@ def run_cte(b=8192, h=16, w=16, n=4, density=0.20, lanes=0):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        # c4 is 65 536 envs over 8 GPUs; here the same envs on ONE GPU: with more than one wave pair per SIMD the
+        # launch cost and the dependent chain of a step are hidden by other workgroups
+        for envs in (16384, 32768, 65536):
+            run("c3_8192x32x32_n8", tag=f"c3 per-env workload, {envs} envs on one GPU", envs=envs, fused_T=20)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cte":
         for lanes in (0, 8, 16, 32, 64):
             run_cte(lanes=lanes)
