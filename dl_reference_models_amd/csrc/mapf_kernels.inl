@@ -428,19 +428,8 @@ __device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, La
     lane_unpack(r, is_agent, st);
 }
 
-// 16-byte state store; MAPF_STATE_STORE: 0 = plain (line stays in L2), 2 = sc1 write-through
-#ifndef MAPF_STATE_STORE
-#define MAPF_STATE_STORE 0
-#endif
-__device__ __forceinline__ void store_state16(void *dst, const uint4 v) {
-#if MAPF_STATE_STORE == 2
-    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    const v4u w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(w) : "memory");
-#else
-    *reinterpret_cast<uint4 *>(dst) = v;
-#endif
-}
+// 16-byte state store (plain: write-through and nontemporal variants were measured and are slower)
+__device__ __forceinline__ void store_state16(void *dst, const uint4 v) { *reinterpret_cast<uint4 *>(dst) = v; }
 
 __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
     uint4 *rp = reinterpret_cast<uint4 *>(rec);
@@ -456,6 +445,40 @@ __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
     store_state16(rp, q0);
     store_state16(rp + 1, q1);
     store_state16(rp + 2, st.dist);
+}
+
+// A full wave's 64 records are 3 KiB of contiguous memory, but lane i owns bytes [48i, 48i + 48): stored from the
+// lanes directly, each of the three 16-byte stores touches all 24 cache lines with a third of their bytes.  Going
+// through LDS turns them into three fully coalesced 1 KiB stores (c3: 6.13 -> 5.71 us per step).
+// MAPF_STATE_POLICY = cache policy of those stores (buffer-store aux bits): 0 plain (measured best), 2 nontemporal
+// (5.75 us), 16 sc1 write-through (5.77 us), 18 both (5.98 us).
+#ifndef MAPF_STATE_POLICY
+#define MAPF_STATE_POLICY 0
+#endif
+typedef unsigned int v4u_state_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_lanes_coalesced(AgentRec *rec0, uint4 *xpose, int lane, const Lane &st) {
+    uint4 q0, q1;
+    q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
+    q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
+    q0.z = (uint32_t)st.moved;
+    q0.w = (uint32_t)(st.moved >> 32);
+    q1.x = (uint32_t)st.failed;
+    q1.y = (uint32_t)(st.failed >> 32);
+    q1.z = (uint32_t)st.progress;
+    q1.w = (uint32_t)(st.progress >> 32);
+    xpose[3 * lane] = q0;
+    xpose[3 * lane + 1] = q1;
+    xpose[3 * lane + 2] = st.dist;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rec0, 0, 64 * 48, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint4 v = xpose[k * 64 + lane];
+        const v4u_state_t w = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (k * 64 + lane) * 16, 0, MAPF_STATE_POLICY);
+    }
 }
 
 __device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
@@ -1051,6 +1074,7 @@ struct Lds {
     uint4 *tab;
     uint4 *otab;  // two-wave step kernels: the entries the observation wave reads (x old|new<<16, y goal, w kObsW*);
                   // two copies, used alternately by consecutive steps of the fused kernel (carve_lds + set_parity)
+    uint4 *xpose;  // 3 KiB: the wave's 64 agent records on their way out (store_lanes_coalesced)
     float *stage;
     int16_t *scratch;
     uint32_t *map;  // [G][H + 2*kRowPad][W + 2*kRowPad] cell words (only when Io::use_map)
@@ -1060,6 +1084,7 @@ __device__ __forceinline__ Lds carve_lds(const Io &io, unsigned char *raw) {
     l.rows = reinterpret_cast<uint64_t *>(raw);
     l.tab = reinterpret_cast<uint4 *>(raw + io.lds_tab_off);
     l.otab = l.tab + 64;
+    l.xpose = l.tab + 192;
     l.stage = reinterpret_cast<float *>(raw + io.lds_stage_off);
     l.scratch = reinterpret_cast<int16_t *>(raw + io.lds_scratch_off);
     l.map = reinterpret_cast<uint32_t *>(raw + io.lds_map_off);
@@ -1155,9 +1180,12 @@ __device__ __forceinline__ void wg_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// rec0 != nullptr (single-step kernel, full wave): the wave's 64 agent records and the envs' counters are stored
+// from inside the body, as soon as they are final, unless an env of the wave resets in this launch; returns
+// whether that happened.
 template <class K, int LPE, int MW, bool FAST, bool DUAL>
-__device__ __forceinline__ void step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                          const int ngroups, int act, Lane &st, int *sc) {
+__device__ __forceinline__ bool step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
+                                          const int ngroups, int act, Lane &st, int *sc, AgentRec *rec0 = nullptr) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const bool env_ok = FAST ? true : (grp < ngroups);
@@ -1433,6 +1461,31 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
 
     reward += term_reward;
     reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
+    // blocking flags feed NEXT step's observation (MA-env:608-625)
+    const bool blocking = is_agent && reached && !moved && po.blocks;
+
+    // ---- everything that does not depend on the lock detector leaves now, ahead of the observation stream of the
+    //      other wave: rewards, per-agent info flags, done flags and (FAST, nobody resets) the agent records ------
+    if (is_agent && !errored) {
+        if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
+        if (io.info_agent) {
+            uchar2 ia;
+            ia.x = blocking ? 1 : 0;
+            ia.y = grs ? 1 : 0;
+            reinterpret_cast<uchar2 *>(io.info_agent)[(size_t)env * N + a] = ia;
+        }
+    }
+    if (env_ok && !errored && a == 0) {
+        if (io.terminated) io.terminated[env] = (uint8_t)term;
+        if (io.truncated) io.truncated[env] = (uint8_t)trunc;
+    }
+    bool records_stored = false;
+    if (FAST && rec0 != nullptr && !__any(do_reset)) {
+        st.pos = cur;
+        st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+        store_lanes_coalesced(rec0, l.xpose, lane, st);
+        records_stored = true;
+    }
 
     // lock detector (MA-env:400-438): deadlock has priority over livelock
     using gm_t = typename GMask<LPE>::type;
@@ -1463,42 +1516,52 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
         sc[MAPF_CTR_LIVELOCK_EVENTS] += ll_event;
     }
 
-    // blocking flags feed NEXT step's observation (MA-env:608-625)
-    const bool blocking = is_agent && reached && !moved && po.blocks;
     const int blocking_step = __popcll(gballot<LPE>(blocking, lane));
     sc[MAPF_CTR_BLOCKING_COUNT] += blocking_step;
 
     MAPF_STAMP(6);
-    // ---- per-step outputs: info (MA-env:627-656), rewards, done flags --------------------------------
+    // ---- per-step outputs that need the lock detector: info (MA-env:627-656) ------------------------------
     {
         const int reached_cnt = __popcll(gballot<LPE>(is_agent && reached, lane));
         const int completed_cnt = __popcll(gballot<LPE>(is_agent && completed, lane));
         const int goals_total = lifelong ? sc[MAPF_CTR_GOALS_REACHED_TOTAL] : reached_cnt;
-        if (io.info_all && env_ok && !errored && a == 0) {
-            const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
-            float *ia = io.info_all + (size_t)env * MAPF_INFO_ALL;  // 56 bytes per env: 8-byte aligned
-            float2 *ia2 = reinterpret_cast<float2 *>(ia);
-            ia2[0] = make_float2((float)goals_step, (float)goals_total);
-            ia2[1] = make_float2((float)blocking_step, (float)sc[MAPF_CTR_BLOCKING_COUNT]);
-            ia2[2] = make_float2((float)deadlock, (float)livelock);
-            ia2[3] = make_float2((float)dl_event, (float)ll_event);
-            ia2[4] = make_float2((float)sc[MAPF_CTR_DEADLOCK_EVENTS], (float)sc[MAPF_CTR_LIVELOCK_EVENTS]);
-            ia2[5] = make_float2((float)sc[MAPF_CTR_DEADLOCK_STEPS], (float)sc[MAPF_CTR_LIVELOCK_STEPS]);
-            ia2[6] = make_float2((float)completed_cnt / (float)N,        // completion_ratio MA-env:638
-                                 (float)goals_total / (float)steps);      // throughput MA-env:655
-        }
-        if (is_agent && !errored) {
-            if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
-            if (io.info_agent) {
-                uchar2 ia;
-                ia.x = blocking ? 1 : 0;
-                ia.y = grs ? 1 : 0;
-                reinterpret_cast<uchar2 *>(io.info_agent)[(size_t)env * N + a] = ia;
+        const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
+        const float2 i0 = make_float2((float)goals_step, (float)goals_total);
+        const float2 i1 = make_float2((float)blocking_step, (float)sc[MAPF_CTR_BLOCKING_COUNT]);
+        const float2 i2 = make_float2((float)deadlock, (float)livelock);
+        const float2 i3 = make_float2((float)dl_event, (float)ll_event);
+        const float2 i4 = make_float2((float)sc[MAPF_CTR_DEADLOCK_EVENTS], (float)sc[MAPF_CTR_LIVELOCK_EVENTS]);
+        const float2 i5 = make_float2((float)sc[MAPF_CTR_DEADLOCK_STEPS], (float)sc[MAPF_CTR_LIVELOCK_STEPS]);
+        const float2 i6 = make_float2((float)completed_cnt / (float)N,        // completion_ratio MA-env:638
+                                      (float)goals_total / (float)steps);      // throughput MA-env:655
+        if (FAST) {
+            // full wave: the G envs own G*56 contiguous bytes of info_all and G*64 of the counters.  Lane 0 of each
+            // group drops its env's values in LDS (the transpose region is free again: same wave, DS ops in order)
+            // and the wave writes each tensor with one store instead of seven (three) partial ones per env.
+            constexpr int G = 64 / LPE;
+            float2 *xi = reinterpret_cast<float2 *>(l.xpose);
+            uint4 *xs = l.xpose + 64;
+            if (a == 0) {
+                float2 *q = xi + grp * 7;
+                q[0] = i0; q[1] = i1; q[2] = i2; q[3] = i3; q[4] = i4; q[5] = i5; q[6] = i6;
+                if (records_stored) {
+                    xs[grp * 3] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+                    xs[grp * 3 + 1] = make_uint4(sc[4], sc[5], sc[6], sc[7]);
+                    xs[grp * 3 + 2] = make_uint4(sc[8], sc[9], sc[10], sc[11]);
+                }
             }
-        }
-        if (env_ok && !errored && a == 0) {
-            if (io.terminated) io.terminated[env] = (uint8_t)term;
-            if (io.truncated) io.truncated[env] = (uint8_t)trunc;
+            wave_lds_sync();
+            if (io.info_all) {
+                float2 *dst = reinterpret_cast<float2 *>(io.info_all + (size_t)env0 * MAPF_INFO_ALL);
+                for (int k = lane; k < G * 7; k += 64) dst[k] = xi[k];
+            }
+            if (records_stored && lane < 3 * G) {  // the counters of an env are its first 48 of 64 bytes
+                const int g = lane / 3, j = lane - 3 * g;
+                store_state16(io.scal + (size_t)(env0 + g) * kScalInts + j * 4, xs[lane]);
+            }
+        } else if (io.info_all && env_ok && !errored && a == 0) {
+            float2 *ia2 = reinterpret_cast<float2 *>(io.info_all + (size_t)env * MAPF_INFO_ALL);  // 56 B per env
+            ia2[0] = i0; ia2[1] = i1; ia2[2] = i2; ia2[3] = i3; ia2[4] = i4; ia2[5] = i5; ia2[6] = i6;
         }
     }
 
@@ -1550,6 +1613,7 @@ __device__ __forceinline__ void step_body(const Params &p, const Io &io, const L
                                  sc, io.obs != nullptr);
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }
+    return records_stored;
 }
 
 // The fused kernel alternates between the two copies of the observation table, so that the state wave may publish
@@ -1679,12 +1743,17 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // attribute the load latency to phase 0->1
 #endif
     MAPF_STAMP(1);
+    bool records_stored = false;
     if (full && !__any(act < 0 || act > 4))
-        step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
+        records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc,
+                                                            io.agents + (size_t)env0 * N);
     else
         step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
-    if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
-    if (env_ok && a == 0) store_scal(io.scal, env, sc);
+    if (!records_stored) {  // otherwise records and counters left from inside the body
+        if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, st);
+        else if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (env_ok && a == 0) store_scal(io.scal, env, sc);
+    }
     MAPF_STAMP(8);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // how long the trailing stores take to drain

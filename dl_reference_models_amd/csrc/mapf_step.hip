@@ -293,7 +293,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.scratch_i16 = (p.hash_cap + 2 * N + 1) & ~1;
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * (H + 2 * kRowPad) * 8) + 15) & ~15;  // kRowPad sentinel rows on either side
-    const int tab_bytes = 3 * 64 * 16;  // one 16-byte entry per lane: pair table + two observation-wave tables
+    // one 16-byte entry per lane: pair table + two observation-wave tables, then 3 KiB for the record transpose
+    const int tab_bytes = 3 * 64 * 16 + 64 * 48;
     const int stage_bytes = ((G * (cte ? (H * W + 5 * N) : N * p.L) * 4) + 15) & ~15;
     const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
     p.lds_tab_off = rows_bytes;
