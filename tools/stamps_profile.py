@@ -45,7 +45,7 @@ for k, nme in enumerate(names):
     print(f"  {nme:22s} median {np.median(d[:, :, k]):9.0f}  mean {d[:, :, k].mean():9.0f}  p95 {np.percentile(d[:, :, k], 95):9.0f}")
 print(f"  {'wave total':22s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f}")
 # (stamps of different XCDs come from different counters: only differences inside one wave/workgroup are meaningful)
-if env.launch_info()["threads"] == 128:  # observation wave, relative to the state wave's first stamp
+if env.launch_info()["threads"] >= 128:  # observation wave, relative to the state wave's first stamp
     w1 = full[:, :, 10:15] - st[:, :, 0:1]
     for k, nme in enumerate(["obs wave: rows loaded (B0)", "obs wave: released (B1)", "obs wave: observation staged",
                              "obs wave: stores issued", "obs wave: stores drained"]):
