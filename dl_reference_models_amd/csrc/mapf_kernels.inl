@@ -655,6 +655,83 @@ __device__ __forceinline__ uint32_t resolve_moves_map(const Params &p, uint32_t 
 // final_state: everybody at their new cell (reset, or after a lifelong respawn MA-env:565-575);
 // otherwise agent i sees agents <= i at their new cell and agents > i at their old one (MA-env:528).
 // ------------------------------------------------------------------------------------------------
+// ---- pieces of an agent's observation, shared by observe() and the precomputing observation wave ----------------
+// obstacle / out-of-bounds bits of the V x V window whose top-left cell is (r0, c0); rows[d] = obstacle row r0 + d
+template <int MW, int MAXV>
+__device__ __forceinline__ WMask<MW> window_obstacles(const uint64_t *rows, int c0, int V, int col_pad) {
+    WMask<MW> obst;
+    obst.clear();
+    if (col_pad) {  // one wave-uniform branch around the whole window, not one per row
+#pragma unroll
+        for (int d = 0; d < MAXV; d++) {
+            if (d < V) obst.or_row(row_window_padded(rows[d], c0, V, col_pad), d * V);
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < MAXV; d++) {
+            if (d < V) obst.or_row(row_window_wide(rows[d], c0, V), d * V);
+        }
+    }
+    return obst;
+}
+// window bit of `cell` (row<<8 | col) or nothing if it lies outside
+template <int MW>
+__device__ __forceinline__ void window_set(WMask<MW> &m, uint32_t cell, int r0, int c0, int V) {
+    const int r = (int)((cell >> 8) & 255u) - r0, c = (int)(cell & 255u) - c0;
+    m.set_if(max((unsigned)r, (unsigned)c) < (unsigned)V, __mul24(r, V) + c);
+}
+// goal delta component (MA-env:330-335): correctly rounded fp32 quotient when normalised
+__device__ __forceinline__ float goal_delta(int d, float den, bool normalise) {
+    const float f = (float)d;
+    return normalise ? f / den : f;
+}
+// the flat observation row (MA-env:306-328) from the window masks: cell codes by priority obstacle / out-of-bounds
+// 1 > other agent 2 > own goal 3 > other goal 4 > empty 0, as three bit planes, four cells per round (bit spread +
+// byte->float converts); then goal delta, optional goal distance, pressure flag, action mask (MA-env:749-773)
+template <class K, int MW, int MAXV>
+__device__ __forceinline__ void emit_obs_row(const Params &p, float *srow, const WMask<MW> &obst, const WMask<MW> &agm,
+                                             const WMask<MW> &goals, const WMask<MW> &own, float gd_r, float gd_c,
+                                             bool pressure) {
+    const int V = K::V(p), sr = K::sr(p), VV = V * V, ctr = sr * V + sr;
+    const uint32_t flags = K::flags(p);
+    const WMask<MW> oa = obst | agm;
+    const WMask<MW> g3 = own.andnot(oa);
+    const WMask<MW> g4 = goals.andnot(oa | own);
+    const WMask<MW> bit0 = obst | g3;
+    const WMask<MW> bit1 = agm.andnot(obst) | g3;
+    constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
+#pragma unroll
+    for (int t0 = 0; t0 < MAXV * MAXV; t0 += 4) {
+        if (t0 < VV) {
+            const uint32_t by = ((bit0.nib(t0) * KS) & MS) | (((bit1.nib(t0) * KS) & MS) << 1) |
+                                (((g4.nib(t0) * KS) & MS) << 2);
+            srow[t0] = (float)(by & 0xFFu);
+            if (t0 + 1 < VV) srow[t0 + 1] = (float)((by >> 8) & 0xFFu);
+            if (t0 + 2 < VV) srow[t0 + 2] = (float)((by >> 16) & 0xFFu);
+            if (t0 + 3 < VV) srow[t0 + 3] = (float)(by >> 24);
+        }
+    }
+    float *q = srow + VV;
+    *q++ = gd_r;
+    *q++ = gd_c;
+    if (flags & MAPF_FLAG_GOAL_DISTANCE) *q++ = fabsf(gd_r) + fabsf(gd_c);
+    if (flags & MAPF_FLAG_BLOCKING_PRESSURE) *q++ = pressure ? 1.0f : 0.0f;
+    if (flags & MAPF_FLAG_ACTION_MASK) {
+        bool up = false, rt = false, dn = false, lf = false;
+        if (sr > 0) {
+            up = !oa.get(ctr - V);
+            rt = !oa.get(ctr + 1);
+            dn = !oa.get(ctr + V);
+            lf = !oa.get(ctr - 1);
+        }
+        q[0] = 1.0f;
+        q[1] = up ? 1.0f : 0.0f;
+        q[2] = rt ? 1.0f : 0.0f;
+        q[3] = dn ? 1.0f : 0.0f;
+        q[4] = lf ? 1.0f : 0.0f;
+    }
+}
+
 struct PairOut {
     uint64_t nbr;   // agents within lock_nearby_manhattan (final positions), self excluded
     int sum_delta;  // sum over {self} U nbr of (distance at window start - distance now)
@@ -785,71 +862,14 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     }
     if (!EMIT || !is_agent) return;
 
-    if (io.col_pad) {  // one wave-uniform branch around the whole window, not one per row
-#pragma unroll
-        for (int d = 0; d < MAXV; d++) {
-            if (d < V) obst.or_row(row_window_padded(rows[d], c0, V, io.col_pad), d * V);
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < MAXV; d++) {
-            if (d < V) obst.or_row(row_window_wide(rows[d], c0, V), d * V);
-        }
-    }
-    const int ctr = sr * V + sr;
-    agm.clear_bit(ctr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
+    obst = window_obstacles<MW, MAXV>(rows, c0, V, io.col_pad);
+    agm.clear_bit(sr * V + sr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
     WMask<MW> own;
     own.clear();
-    {
-        const int gr = (int)((goal >> 8) & 255u) - r0, gc = (int)(goal & 255u) - c0;
-        own.set_if(max((unsigned)gr, (unsigned)gc) < (unsigned)V, __mul24(gr, V) + gc);
-    }
-
-    // cell code priority: obstacle / out-of-bounds 1 > other agent 2 > own goal 3 > other goal 4 > empty 0,
-    // as three bit planes; four cells are converted per round (bit spread + byte->float converts)
-    const WMask<MW> oa = obst | agm;
-    const WMask<MW> g3 = own.andnot(oa);
-    const WMask<MW> g4 = goals.andnot(oa | own);
-    const WMask<MW> bit0 = obst | g3;
-    const WMask<MW> bit1 = agm.andnot(obst) | g3;
-    const int VV = V * V;
-    constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
-#pragma unroll
-    for (int t0 = 0; t0 < MAXV * MAXV; t0 += 4) {
-        if (t0 < VV) {
-            const uint32_t by = ((bit0.nib(t0) * KS) & MS) | (((bit1.nib(t0) * KS) & MS) << 1) |
-                                (((g4.nib(t0) * KS) & MS) << 2);
-            srow[t0] = (float)(by & 0xFFu);
-            if (t0 + 1 < VV) srow[t0 + 1] = (float)((by >> 8) & 0xFFu);
-            if (t0 + 2 < VV) srow[t0 + 2] = (float)((by >> 16) & 0xFFu);
-            if (t0 + 3 < VV) srow[t0 + 3] = (float)(by >> 24);
-        }
-    }
-    float *q = srow + VV;
-    float gd_r = (float)((int)((goal >> 8) & 255u) - myr);
-    float gd_c = (float)((int)(goal & 255u) - myc);
-    if (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) {
-        gd_r = gd_r / io.den_r;
-        gd_c = gd_c / io.den_c;
-    }
-    *q++ = gd_r;
-    *q++ = gd_c;
-    if (flags & MAPF_FLAG_GOAL_DISTANCE) *q++ = fabsf(gd_r) + fabsf(gd_c);
-    if (flags & MAPF_FLAG_BLOCKING_PRESSURE) *q++ = pressure ? 1.0f : 0.0f;
-    if (flags & MAPF_FLAG_ACTION_MASK) {
-        bool up = false, rt = false, dn = false, lf = false;
-        if (sr > 0) {
-            up = !oa.get(ctr - V);
-            rt = !oa.get(ctr + 1);
-            dn = !oa.get(ctr + V);
-            lf = !oa.get(ctr - 1);
-        }
-        q[0] = 1.0f;
-        q[1] = up ? 1.0f : 0.0f;
-        q[2] = rt ? 1.0f : 0.0f;
-        q[3] = dn ? 1.0f : 0.0f;
-        q[4] = lf ? 1.0f : 0.0f;
-    }
+    window_set<MW>(own, goal, r0, c0, V);
+    const bool norm = (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
+    emit_obs_row<K, MW, MAXV>(p, srow, obst, agm, goals, own, goal_delta((int)((goal >> 8) & 255u) - myr, io.den_r, norm),
+                              goal_delta((int)(goal & 255u) - myc, io.den_c, norm), pressure);
 }
 
 // copy the wave's staged observations to global memory.  sel (per lane, uniform inside a group):
@@ -1647,9 +1667,10 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
         observe<K, LPE, MW, kObsEmit, MAP_OK>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
                                               (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po,
                                               l.map + grp * (H + 2 * kRowPad) * map_w);
-    } else
-    observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
-                                         (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po);
+    } else {
+        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
+                                             (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po);
+    }
     wave_lds_sync();
     MAPF_STAMP_W1(12);
     const bool any_reset = __any((w & kObsWReset) != 0);
