@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--graph-steps", type=int, default=100,
                     help="steps captured per hipGraph (0 = plain launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=300)
+    ap.add_argument("--cpu-steps", type=int, default=700)
     ap.add_argument("--kernel-samples", type=int, default=200,
                     help="launches timed one by one with events for the roofline figure")
     return ap.parse_args()

@@ -43,7 +43,11 @@ tot = st[:, :, 9] - st[:, :, 0]
 print(f"workload {name}: {blocks} waves; s_memtime ticks are shader cycles (100 MHz-based clock on gfx950: see guide)")
 for k, nme in enumerate(names):
     print(f"  {nme:22s} median {np.median(d[:, :, k]):9.0f}  mean {d[:, :, k].mean():9.0f}  p95 {np.percentile(d[:, :, k], 95):9.0f}")
-print(f"  {'wave total':22s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f}")
+print(f"  {'wave total':22s} median {np.median(tot):9.0f}  mean {tot.mean():9.0f}  p99 {np.percentile(tot, 99):9.0f}  "
+      f"slowest wave of a launch (median over launches) {np.median(tot.max(axis=1)):9.0f}")
+slow = tot.argmax(axis=1)
+dd = np.stack([d[t, slow[t]] for t in range(d.shape[0])])
+print("  phases of the slowest wave (median over launches): " + " ".join(f"{np.median(dd[:, k]):.0f}" for k in range(dd.shape[1])))
 # (stamps of different XCDs come from different counters: only differences inside one wave/workgroup are meaningful)
 if env.launch_info()["threads"] >= 128:  # observation wave, relative to the state wave's first stamp
     w1 = full[:, :, 10:15] - st[:, :, 0:1]
