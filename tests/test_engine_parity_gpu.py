@@ -230,6 +230,39 @@ def test_state_roundtrip_and_rng_words():
         assert np.array_equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("shape", [(24, 12, 12, 8, {}), (5, 9, 14, 3, {"lifelong_mapf": True}), (3, 20, 20, 20, {})])
+def test_step_with_every_output_null_advances_the_state_identically(shape):
+    """The C ABI allows obs / rewards / flags / info to be NULL (mapf_step.h): the step kernel then runs without
+    its observation wave.  The state after T such steps must equal the state after T ordinary steps (and so must the
+    static-state observation computed from it afterwards)."""
+    import ctypes as C
+    import torch
+
+    b, h, w, n, extra = shape
+    cfg = {"num_agents": n, "sensor_range": 2, "steps_per_episode": 17, "include_action_mask_in_obs": True, **extra}
+    grids = synth_grids(b, h, w, 0.15, n)
+    full = EngineStepper(grids, cfg, seeds=list(range(50, 50 + b)))
+    bare = EngineStepper(grids, cfg, seeds=list(range(50, 50 + b)))
+    full.reset()
+    bare.reset()
+    acts = np.random.default_rng(4).integers(0, 5, size=(40, b, n)).astype(np.int8)
+    env = bare.env
+    for t in range(acts.shape[0]):
+        out = full.env.step(torch.from_numpy(acts[t]).to(full.env.device), auto_reset=False)
+        done = (out["terminated"] | out["truncated"]).bool()
+        a = torch.from_numpy(acts[t]).to(env.device)
+        rc = env._lib.mapf_step(env._h, C.c_void_p(a.data_ptr()), None, None, None, None, None, None, None, 0, env._stream())
+        assert rc == 0
+        if bool(done.any()):  # finished envs are reset explicitly in both engines (same RNG stream)
+            full.env.reset(done.to(torch.uint8))
+            env.reset(done.to(torch.uint8))
+    env.poll_error()
+    sa, sb = full.env.get_state(), env.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(env.observe().cpu().numpy(), full.env.observe().cpu().numpy())
+
+
 @pytest.mark.parametrize("extra", [{}, {"livelock_window_steps": 40, "deadlock_window_steps": 20},
                                    {"lifelong_mapf": True, "livelock_window_steps": 5, "deadlock_window_steps": 3}])
 def test_state_snapshot_resumes_bit_exactly_in_a_fresh_engine(extra):
