@@ -1896,41 +1896,46 @@ struct CteIo {
     int auto_reset;
 };
 
-// full-grid observation + joint mask of the groups' current state -> staging rows
+// full-grid observation + joint mask of the groups' current state -> staging rows, in two parts: the obstacle
+// floats of the whole grid (static: the step kernel's observation wave writes them while the moves are resolved)
+// and the agents / goals / mask on top of them
 template <int LPE>
-__device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const uint64_t *lrows, float *srow,
-                                            bool env_ok, bool is_agent, int a, uint32_t pos, uint32_t goal) {
-    const int H = io.H, W = io.W, HW = H * W;
-    if (env_ok) {
-        if ((W & 3) == 0) {
-            // four cells per lane and round: the lanes of the group take consecutive 4-cell chunks of the row-major
-            // grid; (row, chunk) advance incrementally, so there is no division in the loop
-            const int cpr = W >> 2;                     // chunks per row
-            const int dq_r = LPE / cpr, dq_c = LPE - dq_r * cpr;
-            int r = a / cpr, c = a - r * cpr;
-            constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
-            for (int q = a; q < H * cpr; q += LPE) {
-                const uint32_t nib = (uint32_t)(lrows[r] >> (io.col_pad + 4 * c)) & 15u;
-                const uint32_t by = (nib * KS) & MS;
-                float *d = srow + r * W + 4 * c;
-                d[0] = (float)(by & 0xFFu);
-                d[1] = (float)((by >> 8) & 0xFFu);
-                d[2] = (float)((by >> 16) & 0xFFu);
-                d[3] = (float)(by >> 24);
-                r += dq_r;
-                c += dq_c;
-                if (c >= cpr) {
-                    c -= cpr;
-                    r++;
-                }
-            }
-        } else {
-            for (int r = 0; r < H; r++) {
-                const uint64_t bits = lrows[r] >> io.col_pad;
-                for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
+__device__ __forceinline__ void cte_fill_grid(const CteIo &io, const uint64_t *lrows, float *srow, bool env_ok, int a) {
+    const int H = io.H, W = io.W;
+    if (!env_ok) return;
+    if ((W & 3) == 0) {
+        // four cells per lane and round: the lanes of the group take consecutive 4-cell chunks of the row-major
+        // grid; (row, chunk) advance incrementally, so there is no division in the loop
+        const int cpr = W >> 2;                     // chunks per row
+        const int dq_r = LPE / cpr, dq_c = LPE - dq_r * cpr;
+        int r = a / cpr, c = a - r * cpr;
+        constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
+        for (int q = a; q < H * cpr; q += LPE) {
+            const uint32_t nib = (uint32_t)(lrows[r] >> (io.col_pad + 4 * c)) & 15u;
+            const uint32_t by = (nib * KS) & MS;
+            float *d = srow + r * W + 4 * c;
+            d[0] = (float)(by & 0xFFu);
+            d[1] = (float)((by >> 8) & 0xFFu);
+            d[2] = (float)((by >> 16) & 0xFFu);
+            d[3] = (float)(by >> 24);
+            r += dq_r;
+            c += dq_c;
+            if (c >= cpr) {
+                c -= cpr;
+                r++;
             }
         }
+    } else {
+        for (int r = 0; r < H; r++) {
+            const uint64_t bits = lrows[r] >> io.col_pad;
+            for (int c = a; c < W; c += LPE) srow[r * W + c] = (float)((bits >> c) & 1ull);
+        }
     }
+}
+template <int LPE>
+__device__ __forceinline__ void cte_overlay(const CteIo &io, float *srow, bool is_agent, int a, uint32_t pos,
+                                            uint32_t goal) {
+    const int H = io.H, W = io.W, HW = H * W;
     wave_lds_sync();
     if (is_agent) srow[(goal >> 8) * W + (goal & 255u)] = (float)(2 * a + 3);  // goals first ...
     wave_lds_sync();
@@ -1950,6 +1955,13 @@ __device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const 
         m[4] = y > 0 ? open(x, y - 1) : 0.0f;
     }
     wave_lds_sync();
+}
+template <int LPE>
+__device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const uint64_t *lrows, float *srow,
+                                            bool env_ok, bool is_agent, int a, uint32_t pos, uint32_t goal) {
+    (void)N;
+    cte_fill_grid<LPE>(io, lrows, srow, env_ok, a);
+    cte_overlay<LPE>(io, srow, is_agent, a, pos, goal);
 }
 
 // SA-env:158-191 for the groups with do_reset: one rng.choice(F) (= bounded(F-1)) per attempt, rejection until unique
@@ -2036,16 +2048,23 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     }
 }
 
+// Two waves per workgroup like k_step: wave 1, the observation wave, fetches the obstacle rows, writes the static
+// part of every env's observation row (the obstacle floats of the whole grid: most of this env's work, and
+// independent of the step) while wave 0 resolves the moves, then adds agents, goals and the joint mask once wave 0
+// has published the new positions (B1) and streams the rows out.  kCteW* = flag bits of the published entries.
+constexpr uint32_t kCteWAgent = 1u, kCteWSelShift = 1u, kCteWReset = 8u;
 template <int LPE>
-__global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, const CteIo io) {
+__global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp, const CteIo io) {
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint64_t *lrows = reinterpret_cast<uint64_t *>(lds_raw);
     uint4 *tab = reinterpret_cast<uint4 *>(lds_raw + io.lds_tab_off);
+    uint4 *otab = tab + 64;
     float *stage = reinterpret_cast<float *>(lds_raw + io.lds_stage_off);
     int16_t *scratch = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch_off);
-    const int lane = threadIdx.x, grp = lane / LPE, a = lane % LPE;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
     const int env0 = blockIdx.x * G, ngroups = min(G, io.B - env0), N = p.N, H = io.H, W = io.W;
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
@@ -2054,13 +2073,29 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
     uint4 *tabg = tab + grp * LPE;
     const uint64_t *myrows = lrows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = stage + (size_t)grp * row_len;
+    const bool want_obs = io.obs || io.final_obs;
+    Io fio;
+    fio.obs = io.obs;
+    fio.final_obs = io.final_obs;
 
-    load_rows_to_lds<LPE>(io.grid_rows, H, lrows, lane, env0, ngroups);
+    if (wv == 1) {
+        load_rows_to_lds<LPE>(io.grid_rows, H, lrows, lane, env0, ngroups);
+        wg_sync();  // B0: rows visible to the state wave
+        if (!want_obs) return;
+        cte_fill_grid<LPE>(io, myrows, srow, env_ok, a);
+        wg_sync();  // B1: positions after the move are published
+        const uint4 ent = otab[lane];
+        cte_overlay<LPE>(io, srow, (ent.z & kCteWAgent) != 0, a, ent.x, ent.y);
+        flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, (int)((ent.z >> kCteWSelShift) & 3u), row_len);
+        if (__any((ent.z & kCteWReset) != 0)) wg_sync();  // B2: the state wave re-uses the staging rows for the reset
+        return;
+    }
+
     Lane st;
     load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
     int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
-    wave_lds_sync();
+    wg_sync();  // B0
 
     // invalid action: get_next_position raises mid-loop (SA-env:262, :401-403); agents before it were processed
     const bool bad = is_agent && (act < 0 || act > 4);
@@ -2136,16 +2171,14 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
     const bool done = env_ok && !errored && (term | trunc);
     const bool do_reset = done && io.auto_reset;
 
-    // observation after ALL moves (SA-env:288-293)
+    // observation after ALL moves (SA-env:288-293): hand the new positions to the observation wave
     st.pos = cur;
     st.flags = reached_once ? kFlagReached : 0;
-    Io fio;
-    fio.obs = io.obs;
-    fio.final_obs = io.final_obs;
-    if (io.obs || io.final_obs) {
-        cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, cur, st.goal);
+    if (want_obs) {
         const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-        flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, sel, row_len);
+        otab[lane] = make_uint4(cur, st.goal, (is_agent ? kCteWAgent : 0u) | ((uint32_t)sel << kCteWSelShift) |
+                                                 (do_reset ? kCteWReset : 0u), 0u);
+        wg_sync();  // B1
     }
     if (env_ok && !errored && a == 0) {
         if (io.reward) io.reward[env] = reward;
@@ -2159,7 +2192,8 @@ __global__ __launch_bounds__(64) void k_cte_step(const Params *__restrict__ pp, 
     int blocking_keep = errored ? sc0.z : blocking_total;  // the exception fires before the penalties are booked
 
     if (__any(do_reset)) {
-        wave_lds_sync();
+        if (want_obs) wg_sync();  // B2: the observation wave is done with the staging rows
+        else wave_lds_sync();
         if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
             cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
         if (do_reset) {

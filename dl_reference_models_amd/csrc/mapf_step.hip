@@ -244,9 +244,9 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // one staging row of H*W + 5N floats per env: widen the groups until a wave's rows fit 64 KiB of LDS
         while (lpe < 64 && (64 / lpe) * (c.height * c.width + 5 * c.num_agents) * 4 > 56 * 1024) lpe <<= 1;
         // the work of this env is the H*W observation row, which spreads over however many lanes the group has:
-        // widen until the launch has about two waves per SIMD (measured: 8192 x 16x16 x 4 agents 7.7 -> 6.9 us,
-        // 1024 x 32x32 x 8 agents 9.5 -> 6.2 us)
-        while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < 2048) lpe <<= 1;
+        // widen until the launch has one two-wave workgroup per SIMD (measured with the two-wave kernel:
+        // 8192 x 16x16 x 4 agents 6.2 us at 16 lanes, 5.9 us at 8; 1024 x 32x32 x 8 agents 5.4 us at 64)
+        while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < 1024) lpe <<= 1;
     }
     mapf_engine *e = new mapf_engine();
     e->cfg = c;
@@ -695,7 +695,7 @@ static CteIo make_cte_io(const mapf_engine *e) {
 static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s) {
 #define MAPF_CASE(L)                                                                                                 \
     case L:                                                                                                          \
-        if (step) hipLaunchKernelGGL((k_cte_step<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);   \
+        if (step) hipLaunchKernelGGL((k_cte_step<L>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io);  \
         else hipLaunchKernelGGL((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);      \
         return hipGetLastError();
     switch (e->lpe) {
