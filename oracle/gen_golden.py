@@ -327,6 +327,31 @@ def g2_g3_g4_batches():
     save("g8_widewin_5x5_n5", tr)
 
 
+def g10_wide_groups():
+    """Wide groups recorded from the reference itself: N = 20 finite episodes (32-lane groups: LDS cell map, B1 after
+    the map) with a goal-seeking stream so that episodes also end in success, and N = 40 lifelong on a dense small
+    grid (64-lane groups, many respawns per step, small candidate sets)."""
+    cfg = {"env_name": "synthetic", "num_agents": 20, "sensor_range": 2, "steps_per_episode": 40,
+           "include_action_mask_in_obs": True, "deadlock_window_steps": 4, "livelock_window_steps": 8}
+    B = 3
+    grids = [synth_grid(70_000 + b, 12, 12, 0.12, 40) for b in range(B)]
+    tr = record_trace(cfg, grids, list(range(200, 200 + B)), 130, greedy=0.7)
+    print(f"  g10 n20: goals={tr['info_all'][:, :, 0].sum():.0f} blocking={tr['info_all'][:, :, 2].sum():.0f} "
+          f"dl={tr['info_all'][:, :, 6].sum():.0f} ll={tr['info_all'][:, :, 7].sum():.0f}")
+    assert tr["info_all"][:, :, 0].sum() >= 10
+    save("g10_n20_finite_12x12", tr)
+
+    cfg = {"env_name": "synthetic", "num_agents": 40, "sensor_range": 2, "steps_per_episode": 45,
+           "include_action_mask_in_obs": True, "lifelong_mapf": True, "deadlock_window_steps": 4,
+           "livelock_window_steps": 8}
+    B = 2
+    grids = [synth_grid(80_000 + b, 11, 13, 0.10, 90) for b in range(B)]
+    tr = record_trace(cfg, grids, list(range(300, 300 + B)), 120, greedy=0.7)
+    print(f"  g10 n40 lifelong respawns: {tr['info_all'][:, :, 0].sum():.0f} max/step {tr['info_all'][:, :, 0].max():.0f}")
+    assert tr["info_all"][:, :, 0].max() >= 2
+    save("g10_n40_lifelong_11x13", tr)
+
+
 def g5_named_and_deterministic():
     """Every named grid with its fixed start/goal table (deterministic), 4 or 2 agents."""
     for name in NAMED:
@@ -652,6 +677,7 @@ def main():
     export_named_grids()
     g1_parity_digest()
     g2_g3_g4_batches()
+    g10_wide_groups()
     g5_named_and_deterministic()
     g5_micro_cases()
     g5_error_paths()

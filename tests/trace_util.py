@@ -247,7 +247,7 @@ BATCH_FIXTURES = [
     "g2_c2_16x16_n4", "g2_c2_16x16_n4_greedy", "g3_c3_32x32_n8", "g3b_tight_6x7_n6", "g4_c5_64x64_n64_lifelong",
     "g4b_lifelong_5x9_n10", "g7_c1_10x10_n2", "g8_sr0_nolock_4x5_n3", "g8_sr4_3x4_n1", "g8_widewin_5x5_n5",
     "g5_named_1_1", "g5_named_1_2", "g5_named_1_3", "g5_named_1_4", "g5_named_2_1", "g5_named_2_2", "g5_named_3_1",
-    "g5_named_2_1_b", "g5_det_lifelong_1_4",
+    "g5_named_2_1_b", "g5_det_lifelong_1_4", "g10_n20_finite_12x12", "g10_n40_lifelong_11x13",
 ]
 
 MICRO_CASES = [
