@@ -456,10 +456,7 @@ __device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
 #define MAPF_STATE_POLICY 0
 #endif
 typedef unsigned int v4u_state_t __attribute__((ext_vector_type(4)));
-// rec0 = record of the wave's first agent; `slot` = this lane's record index in the wave (grp * N + a) or -1 for a
-// lane without an agent; `count` = records of the wave (G * N)
-__device__ __forceinline__ void store_lanes_coalesced(AgentRec *rec0, uint4 *xpose, int lane, int slot, int count,
-                                                      const Lane &st) {
+__device__ __forceinline__ void store_lanes_coalesced(AgentRec *rec0, uint4 *xpose, int lane, const Lane &st) {
     uint4 q0, q1;
     q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
     q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
@@ -469,22 +466,18 @@ __device__ __forceinline__ void store_lanes_coalesced(AgentRec *rec0, uint4 *xpo
     q1.y = (uint32_t)(st.failed >> 32);
     q1.z = (uint32_t)st.progress;
     q1.w = (uint32_t)(st.progress >> 32);
-    if (slot >= 0) {
-        xpose[3 * slot] = q0;
-        xpose[3 * slot + 1] = q1;
-        xpose[3 * slot + 2] = st.dist;
-    }
+    xpose[3 * lane] = q0;
+    xpose[3 * lane + 1] = q1;
+    xpose[3 * lane + 2] = st.dist;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rec0, 0, 64 * 48, 0x00020000);
-    const int n16 = 3 * count;  // 16-byte pieces
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const int idx = k * 64 + lane;
-        const uint4 v = xpose[min(idx, n16 - 1)];
+        const uint4 v = xpose[k * 64 + lane];
         const v4u_state_t w = {v.x, v.y, v.z, v.w};
-        if (idx < n16) __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, idx * 16, 0, MAPF_STATE_POLICY);
+        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (k * 64 + lane) * 16, 0, MAPF_STATE_POLICY);
     }
 }
 
@@ -1186,10 +1179,9 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // ------------------------------------------------------------------------------------------------
 // step kernel (MA-env:474-695)
 // ------------------------------------------------------------------------------------------------
-// FAST = every group of the wave is a live env and no agent carries an invalid action: the env-validity predicates
-// are compile-time constants, the error bookkeeping vanishes, and "is this lane an agent" is the lane-only test
-// a < N (itself a constant when N = LPE, as in the BASELINE shapes).  The general body handles the last, ragged
-// workgroup of a batch and the reference's mid-loop ValueError.
+// FAST = the wave is full (every group is a live env, every lane an agent) and no lane carries an invalid
+// action: every validity predicate below is then a compile-time constant and the error bookkeeping vanishes.
+// The general body handles ragged batches, N < LPE and the reference's mid-loop ValueError.
 //
 // DUAL = the workgroup has a second wave, the observation wave (obs_wave_step below): this function is then the
 // state wave.  It publishes what the observation needs in the pair table (entry word w, kObsW*), releases the
@@ -1220,7 +1212,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p), H = io.H, W = io.W;
     const uint32_t flags = K::flags(p);
-    const bool is_agent = FAST ? (a < N) : (env_ok && a < N);
+    const bool is_agent = FAST ? true : (env_ok && a < N);
     const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0;
     const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
@@ -1511,7 +1503,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (FAST && rec0 != nullptr && !__any(do_reset)) {
         st.pos = cur;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
-        store_lanes_coalesced(rec0, l.xpose, lane, is_agent ? grp * N + a : -1, G * N, st);
+        store_lanes_coalesced(rec0, l.xpose, lane, st);
         records_stored = true;
     }
 
@@ -1740,7 +1732,7 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
         return;
     }
 
-    const bool full = ngroups == G;  // wave-uniform: every group of the wave is a live env
+    const bool full = ngroups == G && N == LPE;  // wave-uniform
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
@@ -1758,8 +1750,8 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     __builtin_amdgcn_sched_barrier(0);
     const Lds l = carve_lds(io, lds_raw);
     Lane st;
-    lane_unpack(raw, is_agent, st);
-    act = is_agent ? act : 0;
+    lane_unpack(raw, full || is_agent, st);
+    act = (full || is_agent) ? act : 0;
     MAPF_STAMP(0);
     if (kDual) {
         wg_sync();  // B0
@@ -1779,7 +1771,7 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     else
         step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
     if (!records_stored) {  // otherwise records and counters left from inside the body
-        if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, is_agent ? grp * N + a : -1, G * N, st);
+        if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, st);
         else if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
         if (env_ok && a == 0) store_scal(io.scal, env, sc);
     }
@@ -1836,13 +1828,13 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
         return;
     }
 
-    const bool full = ngroups == G;  // every group of the wave is a live env
+    const bool full = ngroups == G && N == LPE;
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
 
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
     if (kDual) {
@@ -1867,14 +1859,14 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
         if (io.info_all) it.info_all = io.info_all + (size_t)t * io.B * MAPF_INFO_ALL;
         if (io.info_agent) it.info_agent = io.info_agent + (size_t)t * BN * 2;
         int act = (int)io.actions[(size_t)t * BN + (size_t)env * N + min(a, N - 1)];
-        act = is_agent ? act : 0;
+        act = (full || is_agent) ? act : 0;
         if (full && !__any(act < 0 || act > 4))
             step_body<K, LPE, MW, true, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
         else
             step_body<K, LPE, MW, false, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
         wave_lds_sync();  // this wave's staging / table regions are reused by the next step
     }
-    if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);
 }
 
