@@ -387,6 +387,163 @@ __device__ __forceinline__ uint32_t pcg_bounded(Pcg &g, uint32_t rng) {
     return (uint32_t)(m >> 32);
 }
 
+// ---- PCG64 jump-ahead: state_j = A_j * state_0 + S_j * inc (mod 2^128), A_j = M^j, S_j = 1 + M + ... + M^(j-1).
+//      Lets the lanes of a group produce the next outputs of ONE stream side by side (parallel reset sampling). ----
+__device__ const uint64_t kPcgJumpA[65][2] = {  // [j] = {hi, lo}
+    {0x0000000000000000ull, 0x0000000000000001ull},
+    {0x2360ED051FC65DA4ull, 0x4385DF649FCCF645ull},
+    {0x17BCE35BDF69743Cull, 0x529ED9EB20E0AE99ull},
+    {0x25F041404BD80E82ull, 0xEB5AE837ED42153Dull},
+    {0xF4DD417327DB7A9Bull, 0xD194DFBE42D45771ull},
+    {0x16C406E9FBE6C01Full, 0x1712DD28EC4E2775ull},
+    {0x19B2ADD48DEFCDA8ull, 0x81AB1C97E7371089ull},
+    {0x9C49933E0E7F5995ull, 0x3D56ECCA7FE71AEDull},
+    {0x6347AF777A7898F6ull, 0xD1A2D6F33505FFE1ull},
+    {0x18F8F9F7734932A8ull, 0x16509219B4CC2DA5ull},
+    {0xE0928447FDA002F4ull, 0x3520872BC960DB79ull},
+    {0x7FFF9B7984D6798Cull, 0x36814613656D6D9Dull},
+    {0x5673A2CDBFB514C0ull, 0xC86DE54D59EF6951ull},
+    {0xD008599933890BF1ull, 0xFCCE321A884738D5ull},
+    {0x8D76620EAAEC2FFDull, 0x3B7E935CC08AFF69ull},
+    {0xBB65D723FCF3D618ull, 0x2B8DD86F3591BD4Dull},
+    {0xB6A4239F3B315F84ull, 0xF6EF6D3D288C03C1ull},
+    {0x122FCCEAFED32C57ull, 0xEEA812BE56247905ull},
+    {0xA2575AAF626FC8D2ull, 0x96C0E142CF1B6C59ull},
+    {0x5C6A218569CC205Cull, 0x59A6D5EFCA6DB9FDull},
+    {0x01FC86B51903EBA0ull, 0x64AC95EF58E83F31ull},
+    {0xE2266B713B195F27ull, 0xCEC4DF67ED5E1E35ull},
+    {0x8F37EE576D4F4D2Eull, 0xC299A89268A11249ull},
+    {0x49225B7C80456050ull, 0x27D4463AE42813ADull},
+    {0x2EAB8AF607E4C633ull, 0xCB029BDA22918BA1ull},
+    {0x9B752C7238207889ull, 0xDDE45A9B70B35865ull},
+    {0xF8D77BDD4FC33988ull, 0x98027F76E2C3E139ull},
+    {0x7227137533ADDE3Eull, 0xEC0E973139A47A5Dull},
+    {0x9C66D9841EFEA4D2ull, 0x6766F40DDC065911ull},
+    {0xFBA09424C6129045ull, 0x16DDF92EEFD85795ull},
+    {0x7B053022297A0D47ull, 0xD3DBC41FDF34C929ull},
+    {0x4FFF222CCDBFD619ull, 0xC6E06F18A6339E0Dull},
+    {0x2C82901AD1CB0CD1ull, 0x82B631BA6B261781ull},
+    {0x09B2F524AD4778E2ull, 0xBA5E228D55A64BC5ull},
+    {0x3340B19703FE2BEBull, 0x3EB4DDED9E9DBA19ull},
+    {0x444E12C9D609DD48ull, 0xB795FC8124432EBDull},
+    {0x43DBDCEDB0981F9Cull, 0x77A5AC0BF6A136F1ull},
+    {0x155A595EF55BD10Full, 0x5EBBECF3DB4B64F5ull},
+    {0x6C7E40C3C318A6EDull, 0x4E8DA0F12C91A409ull},
+    {0x2D8782C3E5472BA9ull, 0x2A270549450DDC6Dull},
+    {0xC29A3AF9625E59F8ull, 0xABED85A248692761ull},
+    {0x365CA55913F9E80Eull, 0x987FDA77307AD325ull},
+    {0x149559E09D8FB49Cull, 0x639C0B2E547C76F9ull},
+    {0xFA4B8066E6321F2Bull, 0xE1D08A03D54B571Dull},
+    {0xAEDBCDE0C6862989ull, 0x69BDEF77512058D1ull},
+    {0xC92A38F6FEE662F3ull, 0xA85BB0B2889CC655ull},
+    {0x48358C36996266D1ull, 0x64CAEFB64F9322E9ull},
+    {0xE769316CEE909844ull, 0xCCAF328D5EE04ECDull},
+    {0xD6E61FE52FDFEB98ull, 0xA825C00A3C8A3B41ull},
+    {0x652EF16D5960C4C7ull, 0xD7DA7647BCFE6E85ull},
+    {0x1C48D99EF19B5BCDull, 0x9AD9794B1BC397D9ull},
+    {0x5215BFDE6E4E50BFull, 0xEDAED0DD378E737Dull},
+    {0x071D5483DFDC0147ull, 0x63CC9E1586FB3EB1ull},
+    {0xE155A077C32C68B3ull, 0x58C293CCB401FBB5ull},
+    {0xAB4C9B79448B3C1Cull, 0x007735C46BA4C5C9ull},
+    {0xE33ACD710F626603ull, 0x7641B50ACCA4752Dull},
+    {0x9D86EF706106C4CAull, 0xD7145CF783C8D321ull},
+    {0x15FB139EF60C3088ull, 0x176ADE673D4E9DE5ull},
+    {0xF601543BB8EA7814ull, 0xC016FDE81F669CB9ull},
+    {0xAAC2E61C7727D111ull, 0xDC609E1CDBAE03DDull},
+    {0x00147DF1B7837868ull, 0x67928145C4B96891ull},
+    {0xD3234B0DE825F8E7ull, 0xAC55F62D93008515ull},
+    {0xA8A94DEA2829AFDBull, 0x0B63E3D136C20CA9ull},
+    {0x0E60F8FE78F6FAE5ull, 0xC632C3854823CF8Dull},
+    {0xDAB03F988288676Eull, 0xE49E66C4D2746F01ull},
+};
+__device__ const uint64_t kPcgJumpS[65][2] = {  // [j] = {hi, lo}
+    {0x0000000000000000ull, 0x0000000000000000ull},
+    {0x0000000000000000ull, 0x0000000000000001ull},
+    {0x2360ED051FC65DA4ull, 0x4385DF649FCCF646ull},
+    {0x3B1DD060FF2FD1E0ull, 0x9624B94FC0ADA4DFull},
+    {0x610E11A14B07E063ull, 0x817FA187ADEFBA1Cull},
+    {0x55EB531472E35AFFull, 0x53148145F0C4118Dull},
+    {0x6CAF59FE6ECA1B1Eull, 0x6A275E6EDD123902ull},
+    {0x866207D2FCB9E8C6ull, 0xEBD27B06C449498Bull},
+    {0x22AB9B110B39425Cull, 0x292967D144306478ull},
+    {0x85F34A8885B1DB52ull, 0xFACC3EC479366459ull},
+    {0x9EEC447FF8FB0DFBull, 0x111CD0DE2E0291FEull},
+    {0x7F7EC8C7F69B10EFull, 0x463D5809F7636D77ull},
+    {0xFF7E64417B718A7Bull, 0x7CBE9E1D5CD0DB14ull},
+    {0x55F2070F3B269F3Cull, 0x452C836AB6C04465ull},
+    {0x25FA60A86EAFAB2Eull, 0x41FAB5853F077D3Aull},
+    {0xB370C2B7199BDB2Bull, 0x7D7948E1FF927CA3ull},
+    {0x6ED699DB168FB143ull, 0xA9072151352439F0ull},
+    {0x257ABD7A51C110C8ull, 0x9FF68E8E5DB03DB1ull},
+    {0x37AA8A6550943D20ull, 0x8E9EA14CB3D4B6B6ull},
+    {0xDA01E514B30405F3ull, 0x255F828F82F0230Full},
+    {0x366C069A1CD0264Full, 0x7F06587F4D5DDD0Cull},
+    {0x38688D4F35D411EFull, 0xE3B2EE6EA6461C3Dull},
+    {0x1A8EF8C070ED7117ull, 0xB277CDD693A43A72ull},
+    {0xA9C6E717DE3CBE46ull, 0x75117668FC454CBBull},
+    {0xF2E942945E821E96ull, 0x9CE5BCA3E06D6068ull},
+    {0x2194CD8A6666E4CAull, 0x67E8587E02FEEC09ull},
+    {0xBD09F9FC9E875D54ull, 0x45CCB31973B2446Eull},
+    {0xB5E175D9EE4A96DCull, 0xDDCF3290567625A7ull},
+    {0x2808894F21F8751Bull, 0xC9DDC9C1901AA004ull},
+    {0xC46F62D340F719EEull, 0x3144BDCF6C20F915ull},
+    {0xC00FF6F80709AA33ull, 0x4822B6FE5BF950AAull},
+    {0x3B15271A3083B77Bull, 0x1BFE7B1E3B2E19D3ull},
+    {0x8B144946FE438D94ull, 0xE2DEEA36E161B7E0ull},
+    {0xB796D961D00E9A66ull, 0x65951BF14C87CF61ull},
+    {0xC149CE867D561349ull, 0x1FF33E7EA22E1B26ull},
+    {0xF48A801D81543F34ull, 0x5EA81C6C40CBD53Full},
+    {0x38D892E7575E1C7Dull, 0x163E18ED650F03FCull},
+    {0x7CB46FD507F63C19ull, 0x8DE3C4F95BB03AEDull},
+    {0x920EC933FD520D28ull, 0xEC9FB1ED36FB9FE2ull},
+    {0xFE8D09F7C06AB416ull, 0x3B2D52DE638D43EBull},
+    {0x2C148CBBA5B1DFBFull, 0x65545827A89B2058ull},
+    {0xEEAEC7B5081039B8ull, 0x1141DDC9F10447B9ull},
+    {0x250B6D0E1C0A21C6ull, 0xA9C1B841217F1ADEull},
+    {0x39A0C6EEB999D663ull, 0x0D5DC36F75FB91D7ull},
+    {0x33EC47559FCBF58Eull, 0xEF2E4D734B46E8F4ull},
+    {0xE2C8153666521F18ull, 0x58EC3CEA9C6741C5ull},
+    {0xABF24E2D6538820Cull, 0x0147ED9D2504081Aull},
+    {0xF427DA63FE9AE8DDull, 0x6612DD5374972B03ull},
+    {0xDB910BD0ED2B8122ull, 0x32C20FE0D37779D0ull},
+    {0xB2772BB61D0B6CBAull, 0xDAE7CFEB1001B511ull},
+    {0x17A61D23766C3182ull, 0xB2C24632CD002396ull},
+    {0x33EEF6C268078D50ull, 0x4D9BBF7DE8C3BB6Full},
+    {0x8604B6A0D655DE10ull, 0x3B4A905B20522EECull},
+    {0x8D220B24B631DF57ull, 0x9F172E70A74D6D9Dull},
+    {0x6E77AB9C795E480Aull, 0xF7D9C23D5B4F6952ull},
+    {0x19C44715BDE98426ull, 0xF850F801C6F42F1Bull},
+    {0xFCFF1486CD4BEA2Aull, 0x6E92AD0C9398A448ull},
+    {0x9A8603F72E52AEF5ull, 0x45A70A0417617769ull},
+    {0xB0811796245EDF7Dull, 0x5D11E86B54B0154Eull},
+    {0xA6826BD1DD495792ull, 0x1D28E6537416B207ull},
+    {0x514551EE547128A3ull, 0xF98984704FC4B5E4ull},
+    {0x5159CFE00BF4A10Cull, 0x611C05B6147E1E75ull},
+    {0x247D1AEDF41A99F4ull, 0x0D71FBE3A77EA38Aull},
+    {0xCD2668D81C4449CFull, 0x18D5DFB4DE40B033ull},
+    {0xDB8761D6953B44B4ull, 0xDF08A33A26647FC0ull},
+};
+struct U128 {
+    uint64_t hi, lo;
+};
+__device__ __forceinline__ U128 mul128(U128 x, U128 y) {  // low 128 bits of the product
+    U128 r;
+    r.lo = x.lo * y.lo;
+    r.hi = __umul64hi(x.lo, y.lo) + x.lo * y.hi + x.hi * y.lo;
+    return r;
+}
+__device__ __forceinline__ U128 add128(U128 x, U128 y) {
+    U128 r;
+    r.lo = x.lo + y.lo;
+    r.hi = x.hi + y.hi + (r.lo < x.lo ? 1ull : 0ull);
+    return r;
+}
+__device__ __forceinline__ uint64_t pcg_output(U128 st) {  // XSL-RR of a state
+    const uint64_t x = st.hi ^ st.lo;
+    const unsigned rot = (unsigned)(st.hi >> 58);
+    return (x >> rot) | (x << ((64 - rot) & 63));
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-lane register image of an agent
 // ------------------------------------------------------------------------------------------------
@@ -1004,6 +1161,125 @@ __device__ __forceinline__ uint4 static_entry(uint32_t pos, uint32_t goal) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// generate_starts_goals (MA-env:267-282), idx = rng.choice(F, 2N, replace=False), spread over the lanes of the group.
+// NumPy's algorithm is sequential -- Floyd's sampling (2N bounded draws, "already chosen -> take j instead") and a
+// tail shuffle (2N - 1 bounded draws) on ONE PCG64 stream -- and a wave that resets an env sets the duration of the
+// launch for everybody.  What is sequential about it is small, though:
+//   * the raw 64-bit outputs only depend on the stream: lane q computes state_q by jump-ahead (kPcgJump*);
+//   * every draw's bound is known up front (Floyd: j = F - 2N + k, shuffle: i = 2N - 1, ..., 1), so all Lemire
+//     products are formed side by side; a rejection (probability < 2N / 2^32 per draw) or F = 2N (a draw with bound 0
+//     consumes nothing) sends the group to the sequential restatement instead;
+//   * Floyd's membership test is a ballot over the lanes that hold the chosen values (no hash set);
+//   * the shuffle swaps run on the LDS copy.
+// Scratch of the group: raw32[4N + 2] | vals[4N] (uint16) | out[2N] (int16).  Returns false for a group that has to
+// take the sequential path; on true, out (at scratch + kSampleOutOff(N)) holds idx and the stream state is stored.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sample_out_off_i16(int N) { return 2 * (4 * N + 2) + 4 * N; }
+
+template <int LPE>
+__device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, int16_t *scr, int lane, int a, int env,
+                                                             bool env_ok, bool do_reset, int N) {
+    const int size = 2 * N, D = 2 * size - 1;  // bounded draws of one reset
+    uint32_t *raw = reinterpret_cast<uint32_t *>(scr);
+    uint16_t *vals = reinterpret_cast<uint16_t *>(raw + 4 * N + 2);
+    int16_t *out = scr + sample_out_off_i16(N);
+    Pcg g;
+    g.shi = g.slo = g.ihi = g.ilo = 0;
+    g.has32 = g.uinteger = 0;
+    int pop = size + 1;
+    if (do_reset) {
+        pcg_load(g, p.rng + (size_t)env * 6);
+        pop = p.n_free[env];
+    }
+    bool ok = do_reset && pop > size;
+    const int has = (int)g.has32;
+    const int nout = (D - has + 1) >> 1;  // 64-bit outputs consumed; the stream of 32-bit halves is
+                                          // [buffered half if has] lo(o1) hi(o1) lo(o2) hi(o2) ...
+    const U128 s0 = {g.shi, g.slo}, inc = {g.ihi, g.ilo};
+    const U128 stride_a = {kPcgJumpA[LPE][0], kPcgJumpA[LPE][1]};
+    const U128 stride_c = mul128(U128{kPcgJumpS[LPE][0], kPcgJumpS[LPE][1]}, inc);
+    U128 st = s0, fin = s0;
+    uint32_t fin_hi32 = 0;
+    for (int q = a + 1; q <= nout; q += LPE) {
+        if (q == a + 1)
+            st = add128(mul128(U128{kPcgJumpA[q][0], kPcgJumpA[q][1]}, s0), mul128(U128{kPcgJumpS[q][0], kPcgJumpS[q][1]}, inc));
+        else
+            st = add128(mul128(stride_a, st), stride_c);
+        const uint64_t o = pcg_output(st);
+        raw[has + 2 * (q - 1)] = (uint32_t)o;
+        raw[has + 2 * (q - 1) + 1] = (uint32_t)(o >> 32);
+        if (q == nout) {
+            fin = st;
+            fin_hi32 = (uint32_t)(o >> 32);
+        }
+    }
+    if (has && a == 0) raw[0] = g.uinteger;
+    wave_lds_sync();
+    // all bounded draws at once: vals[k] = (raw[k] * (bound_k + 1)) >> 32 unless Lemire would reject
+    bool rej = false;
+    for (int k = a; k < D; k += LPE) {
+        const uint32_t rng = (uint32_t)(k < size ? pop - size + k : size - 1 - (k - size));
+        const uint32_t excl = rng + 1u;
+        const uint64_t m = (uint64_t)raw[k] * excl;
+        const uint32_t left = (uint32_t)m;
+        if (left < excl) rej |= left < (0xFFFFFFFFu - rng) % excl;
+        vals[k] = (uint16_t)(m >> 32);
+    }
+    ok = ok && gballot<LPE>(rej, lane) == 0;
+    wave_lds_sync();
+    // Floyd: lane t holds the chosen values number t and t + LPE
+    int c0 = -1, c1 = -1;
+    for (int k = 0; k < size; k++) {
+        const int val = (int)vals[k], j = pop - size + k;
+        const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+        const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
+        if (a == (k & (LPE - 1))) {
+            if (k < LPE) c0 = chosen;
+            else c1 = chosen;
+        }
+    }
+    // _shuffle_int tail shuffle with the precomputed indices.  Up to 16 entries the permutation fits one 64-bit
+    // register as nibbles: every lane applies the swaps to it (no memory in the dependent chain) and then places
+    // its chosen values; longer index lists are swapped in LDS by one lane.
+    if (size <= 16) {
+        uint64_t perm = 0xFEDCBA9876543210ull;  // nibble x = which chosen value ends up at position x
+        for (int i = size - 1; i >= 1; i--) {
+            const int j = (int)vals[size + (size - 1 - i)];
+            const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 15ull;
+            perm ^= (d << (4 * i)) | (d << (4 * j));
+        }
+        // chosen value t sits at the position x with nibble x == t: scatter through LDS, then every position is read
+        uint8_t *inv = reinterpret_cast<uint8_t *>(out + size);  // [16] position of chosen value t
+        for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
+        wave_lds_sync();
+        if (a < size) out[inv[a]] = (int16_t)c0;
+        if (a + LPE < size) out[inv[a + LPE]] = (int16_t)c1;
+    } else {
+        if (a < size) out[a] = (int16_t)c0;
+        if (a + LPE < size) out[a + LPE] = (int16_t)c1;
+        wave_lds_sync();
+        if (ok && a == 0) {
+            for (int i = size - 1; i >= 1; i--) {
+                const int j = (int)vals[size + (size - 1 - i)];
+                const int16_t t = out[j];
+                out[j] = out[i];
+                out[i] = t;
+            }
+        }
+    }
+    // the stream after D draws: state_nout; a half is left in the buffer when the number of halves used is odd
+    if (ok && env_ok && ((nout - 1) % LPE) == a) {
+        Pcg f;
+        f.shi = fin.hi; f.slo = fin.lo; f.ihi = g.ihi; f.ilo = g.ilo;
+        f.has32 = (uint32_t)(has + 2 * nout - D);
+        f.uinteger = fin_hi32;  // NumPy keeps the last high half in the buffer field even once it has been handed out
+        pcg_store(f, p.rng + (size_t)env * 6);
+    }
+    wave_lds_sync();
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
 // reset() of the groups with do_reset set (MA-env:440-472).  Group-uniform inputs; called under a
 // wave-uniform branch.  Updates lane state + scalars; stages the reset observation when want_obs.
 // ------------------------------------------------------------------------------------------------
@@ -1015,41 +1291,47 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
     if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
         // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False)
         int16_t *hs = scratch + grp * p.scratch_i16;
-        int16_t *out = hs + p.hash_cap;
-        if (do_reset && a == 0) {
-            Pcg g;
-            pcg_load(g, p.rng + (size_t)env * 6);
-            const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
-            for (int k = 0; k < hash_cap; k++) hs[k] = -1;
-            for (int j = pop - size; j < pop; j++) {  // Floyd
-                int val = (int)pcg_bounded(g, (uint32_t)j);
-                int loc = val & mask;
-                // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
-                // probe counters only make termination structural
-                for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
-                if (hs[loc] == -1) {
-                    hs[loc] = (int16_t)val;
-                    out[j - pop + size] = (int16_t)val;
-                } else {
-                    loc = j & mask;
-                    for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
-                    hs[loc] = (int16_t)j;
-                    out[j - pop + size] = (int16_t)j;
+        const int16_t *out = hs + sample_out_off_i16(N);
+        const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, do_reset, N);
+        if (__any(do_reset && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
+            int16_t *outs = hs + p.hash_cap;
+            if (do_reset && !sampled && a == 0) {
+                Pcg g;
+                pcg_load(g, p.rng + (size_t)env * 6);
+                const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
+                for (int k = 0; k < hash_cap; k++) hs[k] = -1;
+                for (int j = pop - size; j < pop; j++) {  // Floyd
+                    int val = (int)pcg_bounded(g, (uint32_t)j);
+                    int loc = val & mask;
+                    // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
+                    // probe counters only make termination structural
+                    for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                    if (hs[loc] == -1) {
+                        hs[loc] = (int16_t)val;
+                        outs[j - pop + size] = (int16_t)val;
+                    } else {
+                        loc = j & mask;
+                        for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                        hs[loc] = (int16_t)j;
+                        outs[j - pop + size] = (int16_t)j;
+                    }
                 }
+                for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
+                    int j = (int)pcg_bounded(g, (uint32_t)i);
+                    int16_t t = outs[j];
+                    outs[j] = outs[i];
+                    outs[i] = t;
+                }
+                if (env_ok) pcg_store(g, p.rng + (size_t)env * 6);
             }
-            for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
-                int j = (int)pcg_bounded(g, (uint32_t)i);
-                int16_t t = out[j];
-                out[j] = out[i];
-                out[i] = t;
-            }
-            if (env_ok) pcg_store(g, p.rng + (size_t)env * 6);
+            wave_lds_sync();
+            if (do_reset && !sampled) out = outs;
         }
-        wave_lds_sync();
         if (do_reset && is_agent) {
             const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
-            st.start = fc[out[a]];
-            st.goal = fc[out[N + a]];
+            const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+            st.start = fc[min(max((int)out[a], 0), top)];
+            st.goal = fc[min(max((int)out[N + a], 0), top)];
         }
         wave_lds_sync();
     }

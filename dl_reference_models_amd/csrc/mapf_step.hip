@@ -290,7 +290,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; m |= m >> 32;
         p.hash_cap = (int)(m + 1);
     }
-    p.scratch_i16 = (p.hash_cap + 2 * N + 1) & ~1;
+    // reset scratch per group: sequential path hash set + idx (hash_cap + 2N), parallel path raw32[4N + 2] | vals[4N] | idx[2N] | 16 bytes
+    p.scratch_i16 = p.hash_cap + 2 * N + 1;
+    if (p.scratch_i16 < 2 * (4 * N + 2) + 4 * N + 2 * N + 8) p.scratch_i16 = 2 * (4 * N + 2) + 4 * N + 2 * N + 8;
+    p.scratch_i16 = (p.scratch_i16 + 7) & ~7;  // 16-byte multiple
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * (H + 2 * kRowPad) * 8) + 15) & ~15;  // kRowPad sentinel rows on either side
     // one 16-byte entry per lane: pair table + two observation-wave tables, then 3 KiB for the record transpose

@@ -22,7 +22,7 @@ def timed(fn, n):
     return e0.elapsed_time(e1) * 1e-3
 
 
-def run(name, over=None, fused_T=100, p=None, tag=None, envs=None):
+def run(name, over=None, fused_T=100, p=None, tag=None, envs=None, stagger=False):
     b, h, w, n, density, _ = wl.WORKLOADS[name]
     if envs is not None:  # batch-size sweep: the same per-env workload, more envs on the one GPU
         b = envs
@@ -30,6 +30,10 @@ def run(name, over=None, fused_T=100, p=None, tag=None, envs=None):
     cfg.update(over or {})
     env = VecReferenceModel(cfg)
     env.reset()
+    if stagger:  # every env starts its first episode at a different step count: ~1 % of the envs reset in EVERY step
+        c = env.get_state()["counters"].copy()
+        c[:, 0] = np.arange(b) % int(cfg["steps_per_episode"])
+        env.set_state(counters=c)
     rng = np.random.default_rng(999)
     pool = 100
     if p is None:
@@ -124,5 +128,6 @@ if __name__ == "__main__":
     run("c3_8192x32x32_n8", {"include_action_mask_in_obs": False}, tag="c3 reference-default obs (mask off, L=28)")
     run("c3_8192x32x32_n8", p=[0.1, 0.1, 0.3, 0.4, 0.1], tag="c3 goal-biased action stream")
     run("c3_8192x32x32_n8", {"force_generic_kernel": True}, tag="c3 runtime-config kernel")
+    run("c3_8192x32x32_n8", stagger=True, tag="c3 with staggered episodes (some env resets in every step)")
     run("c2_1024x16x16_n4")
     run("c5_1024x64x64_n64_lifelong")
