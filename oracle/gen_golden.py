@@ -352,6 +352,22 @@ def g10_wide_groups():
     save("g10_n40_lifelong_11x13", tr)
 
 
+def g11_exactly_2n_free_cells():
+    """F == 2N: rng.choice(F, 2N, replace=False) starts Floyd at j = 0, and a bounded draw with bound 0 consumes no
+    random number -- the alignment of the whole stream depends on it.  Several resets per env."""
+    n, h, w = 3, 4, 6
+    rng = np.random.default_rng(8)
+    grids = []
+    for _ in range(4):
+        g = np.ones((h, w), np.uint8)
+        g.reshape(-1)[rng.choice(h * w, size=2 * n, replace=False)] = 0
+        grids.append(g)
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 1, "steps_per_episode": 7,
+           "include_action_mask_in_obs": True}
+    tr = record_trace(cfg, grids, list(range(700, 704)), 60)
+    save("g11_f_equals_2n_4x6_n3", tr)
+
+
 def g5_named_and_deterministic():
     """Every named grid with its fixed start/goal table (deterministic), 4 or 2 agents."""
     for name in NAMED:
@@ -678,6 +694,7 @@ def main():
     g1_parity_digest()
     g2_g3_g4_batches()
     g10_wide_groups()
+    g11_exactly_2n_free_cells()
     g5_named_and_deterministic()
     g5_micro_cases()
     g5_error_paths()

@@ -230,6 +230,24 @@ def test_state_roundtrip_and_rng_words():
         assert np.array_equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("n", [3, 8])
+def test_reset_with_exactly_2n_free_cells_takes_the_sequential_sampler(n):
+    """F == 2N: the first Floyd draw has bound 0 and consumes no random number (NumPy returns the offset without
+    drawing), so the in-kernel reset leaves its parallel sampler for the sequential restatement.  Several resets in
+    a row against the oracle pin the stream alignment."""
+    h, w = 4, 2 * n  # 8N cells, 2N of them free
+    grids = np.ones((6, h, w), np.uint8)
+    rng = np.random.default_rng(8)
+    for b in range(grids.shape[0]):
+        free = rng.choice(h * w, size=2 * n, replace=False)
+        grids[b].reshape(-1)[free] = 0
+    cfg = {"num_agents": n, "sensor_range": 1, "steps_per_episode": 7, "include_action_mask_in_obs": True}
+    seeds = list(range(700, 706))
+    acts = np.random.default_rng(9).integers(0, 5, size=(40, grids.shape[0], n)).astype(np.int8)
+    stats = compare_steppers(EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds), acts)
+    assert stats["episodes"] >= 5 * grids.shape[0]
+
+
 @pytest.mark.parametrize("shape", [(24, 12, 12, 8, {}), (5, 9, 14, 3, {"lifelong_mapf": True}), (3, 20, 20, 20, {})])
 def test_step_with_every_output_null_advances_the_state_identically(shape):
     """The C ABI allows obs / rewards / flags / info to be NULL (mapf_step.h): the step kernel then runs without

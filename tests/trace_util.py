@@ -248,6 +248,7 @@ BATCH_FIXTURES = [
     "g4b_lifelong_5x9_n10", "g7_c1_10x10_n2", "g8_sr0_nolock_4x5_n3", "g8_sr4_3x4_n1", "g8_widewin_5x5_n5",
     "g5_named_1_1", "g5_named_1_2", "g5_named_1_3", "g5_named_1_4", "g5_named_2_1", "g5_named_2_2", "g5_named_3_1",
     "g5_named_2_1_b", "g5_det_lifelong_1_4", "g10_n20_finite_12x12", "g10_n40_lifelong_11x13",
+    "g11_f_equals_2n_4x6_n3",
 ]
 
 MICRO_CASES = [
