@@ -260,6 +260,14 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// LDS hand-off between the two waves of a workgroup.  Not __syncthreads(): that also waits for the wave's global
+// stores (vmcnt(0)), i.e. for the write-through observation stream to reach memory, once per barrier.  Only LDS
+// contents are exchanged here, so the wave waits for its own DS operations and then joins the barrier.
+__device__ __forceinline__ void wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ------------------------------------------------------------------------------------------------
 // V x V window bit masks (bit dr*V+dc); MW = 32 (V <= 5), 64 (V <= 7), 128 (V <= 11)
@@ -1227,26 +1235,42 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
     }
     ok = ok && gballot<LPE>(rej, lane) == 0;
     wave_lds_sync();
-    // Floyd: lane t holds the chosen values number t and t + LPE
+    // Floyd: lane t holds the chosen values number t and t + LPE.  Up to 16 entries (N <= 8) the drawn values live
+    // in registers (static indices: the loops are unrolled to 16 and predicated), so the dependent chain of an
+    // iteration is compare -> ballot -> select with no LDS access in it.
     int c0 = -1, c1 = -1;
-    for (int k = 0; k < size; k++) {
-        const int val = (int)vals[k], j = pop - size + k;
-        const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
-        const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
-        if (a == (k & (LPE - 1))) {
-            if (k < LPE) c0 = chosen;
-            else c1 = chosen;
-        }
-    }
-    // _shuffle_int tail shuffle with the precomputed indices.  Up to 16 entries the permutation fits one 64-bit
-    // register as nibbles: every lane applies the swaps to it (no memory in the dependent chain) and then places
-    // its chosen values; longer index lists are swapped in LDS by one lane.
     if (size <= 16) {
+        uint32_t vw[8], jw[8];  // vals[0 .. 16) and vals[size .. size + 16) as packed pairs
+        const uint32_t *v32 = reinterpret_cast<const uint32_t *>(vals);
+        const uint32_t *j32 = reinterpret_cast<const uint32_t *>(vals + size);  // size is even: 4-byte aligned
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            vw[q] = v32[q];
+            jw[q] = j32[q];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k < size) {
+                const int val = (int)((vw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), j = pop - size + k;
+                const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+                const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
+                if (a == (k & (LPE - 1))) {
+                    if (k < LPE) c0 = chosen;
+                    else c1 = chosen;
+                }
+            }
+        }
+        // _shuffle_int tail shuffle with the precomputed indices: the permutation fits one 64-bit register as
+        // nibbles; every lane applies the swaps to it and then places its chosen values
         uint64_t perm = 0xFEDCBA9876543210ull;  // nibble x = which chosen value ends up at position x
-        for (int i = size - 1; i >= 1; i--) {
-            const int j = (int)vals[size + (size - 1 - i)];
-            const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 15ull;
-            perm ^= (d << (4 * i)) | (d << (4 * j));
+#pragma unroll
+        for (int t = 0; t < 15; t++) {
+            if (t < size - 1) {
+                const int i = size - 1 - t;
+                const int j = (int)((jw[t >> 1] >> (16 * (t & 1))) & 0xFFFFu);
+                const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 15ull;
+                perm ^= (d << (4 * i)) | (d << (4 * j));
+            }
         }
         // chosen value t sits at the position x with nibble x == t: scatter through LDS, then every position is read
         uint8_t *inv = reinterpret_cast<uint8_t *>(out + size);  // [16] position of chosen value t
@@ -1255,10 +1279,19 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
         if (a < size) out[inv[a]] = (int16_t)c0;
         if (a + LPE < size) out[inv[a + LPE]] = (int16_t)c1;
     } else {
+        for (int k = 0; k < size; k++) {
+            const int val = (int)vals[k], j = pop - size + k;
+            const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+            const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
+            if (a == (k & (LPE - 1))) {
+                if (k < LPE) c0 = chosen;
+                else c1 = chosen;
+            }
+        }
         if (a < size) out[a] = (int16_t)c0;
         if (a + LPE < size) out[a + LPE] = (int16_t)c1;
         wave_lds_sync();
-        if (ok && a == 0) {
+        if (ok && a == 0) {  // longer index lists are swapped in LDS by one lane
             for (int i = size - 1; i >= 1; i--) {
                 const int j = (int)vals[size + (size - 1 - i)];
                 const int16_t t = out[j];
@@ -1286,7 +1319,8 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, const uint64_t *lrows, uint4 *tab, float *stage,
                                              int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
-                                             bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs) {
+                                             bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs,
+                                             bool obs_wave_barrier = false) {
     const int N = K::N(p);
     if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
         // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False)
@@ -1350,6 +1384,9 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         sc[MAPF_CTR_LIVELOCK_STEPS] = 0;
         sc[MAPF_CTR_LOCK_STATE_PREV] = 0;
     }
+    // Two-wave step kernel: the sampling above only touched the group's scratch, so it ran beside the observation wave;
+    // pair table and staging rows are that wave's until it has passed B2.
+    if (obs_wave_barrier) wg_sync();  // B2
     if (want_obs) {
         uint4 *tabg = tab + grp * LPE;
         tabg[a] = static_entry(st.pos, st.goal);
@@ -1473,14 +1510,6 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // bandwidth or issue slots; the split takes the observation (about a third of the instructions) off that path.
 constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSelShift = 3u, kObsWFast = 32u,
                    kObsWReset = 64u;
-// LDS hand-off between the two waves of a workgroup.  Not __syncthreads(): that also waits for the wave's global
-// stores (vmcnt(0)), i.e. for the write-through observation stream to reach memory, once per barrier.  Only LDS
-// contents are exchanged here, so the wave waits for its own DS operations and then joins the barrier.
-__device__ __forceinline__ void wg_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // rec0 != nullptr (single-step kernel, full wave): the wave's 64 agent records and the envs' counters are stored
 // from inside the body, as soon as they are final, unless an env of the wave resets in this launch; returns
@@ -1909,10 +1938,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     //      reset() right after a done step) ------------------------------------------------------------
     if (__any(do_reset)) {
         if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
-        if (obs_wave) wg_sync();  // B2: the observation wave is done with the table and the staging rows
-        else wave_lds_sync();
+        wave_lds_sync();
         reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
-                                 sc, io.obs != nullptr);
+                                 sc, io.obs != nullptr, obs_wave);  // B2 inside: after the sampling, before the observation
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     }
     return records_stored;

@@ -17,11 +17,17 @@ os.environ["MAPF_LIB"] = so
 import torch
 from dl_reference_models_amd import workloads as wl
 from dl_reference_models_amd.vec_env import VecReferenceModel
-name = sys.argv[1] if len(sys.argv) > 1 else wl.HEADLINE
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+stagger = "--stagger" in sys.argv  # spread the episode boundaries: some env of the batch resets in every step
+name = args[0] if args else wl.HEADLINE
 b = wl.WORKLOADS[name][0]
 cfg = wl.workload_config(name, list(range(b)))
 env = VecReferenceModel(cfg)
 env.reset()
+if stagger:
+    c = env.get_state()["counters"].copy()
+    c[:, 0] = np.arange(b) % int(cfg["steps_per_episode"])
+    env.set_state(counters=c)
 acts = torch.randint(0, 5, (64, b, cfg["num_agents"]), dtype=torch.int8, device=env.device)
 for t in range(130):
     env.step(acts[t % 64])
