@@ -1153,13 +1153,21 @@ __device__ __forceinline__ void flush_rows(const Io &io, const float *stage, int
         }
         return;
     }
+    // mixed destinations (typically: one env of the wave resets): one run per group, 16 bytes per lane when the rows
+    // are 16-byte multiples (then every row start is aligned as well)
     for (int g = 0; g < ngroups; g++) {
         const int sg = __shfl(sel, g * LPE, 64);
         float *base = sg == 0 ? io.obs : (sg == 1 ? io.final_obs : nullptr);
         if (!base) continue;
         float *dst = base + (size_t)(env0 + g) * NL;
         const float *src = stage + g * NL;
-        for (int k = lane; k < NL; k += 64) dst[k] = src[k];
+        if ((NL & 3) == 0) {
+            const ObsSink sink = make_obs_sink(dst, (unsigned)NL * 4u);
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            for (int k = lane; k < (NL >> 2); k += 64) store_obs4(sink, (unsigned)k * 16u, s4[k]);
+        } else {
+            for (int k = lane; k < NL; k += 64) dst[k] = src[k];
+        }
     }
 }
 
