@@ -23,7 +23,7 @@ HEADERS = [os.path.join(ROOT, "include", "mapf_step.h")]
 # NOTE: no -ffast-math -- goal_delta needs the correctly rounded fp32 divide.
 # -amdgpu-kernarg-preload-count: gfx950 delivers the first 16 kernarg dwords in SGPRs at wave launch, so the
 #   wave's first state loads do not sit behind a scalar-load round trip (Io is ordered hot-fields-first for it).
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
                "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 

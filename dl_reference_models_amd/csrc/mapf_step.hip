@@ -369,21 +369,16 @@ static int alloc_device_state(mapf_engine *e) {
 
 int mapf_destroy(mapf_handle e) {
     if (!e) return MAPF_OK;
-    hipSetDevice(e->cfg.device);
-    hipFree(e->d_agents);
-    hipFree(e->d_scal);
-    hipFree(e->d_ring);
-    hipFree(e->d_rng);
-    hipFree(e->d_rows);
-    hipFree(e->d_free_cells);
-    hipFree(e->d_free_rank);
-    hipFree(e->d_n_free);
-    hipFree(e->d_err);
-    hipFree(e->d_ep_acc);
-    hipFree(e->d_params);
-    hipFree(e->d_dbg);
+    // best effort: a failing free at teardown is reported through the return code, the handle goes away regardless
+    hipError_t first = hipSetDevice(e->cfg.device);
+    void *const bufs[] = {e->d_agents, e->d_scal, e->d_ring, e->d_rng, e->d_rows, e->d_free_cells, e->d_free_rank,
+                          e->d_n_free, e->d_err, e->d_ep_acc, e->d_params, e->d_dbg};
+    for (void *b : bufs) {
+        const hipError_t rc = hipFree(b);
+        if (first == hipSuccess) first = rc;
+    }
     delete e;
-    return MAPF_OK;
+    return first == hipSuccess ? MAPF_OK : MAPF_ERR_HIP;
 }
 
 int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
