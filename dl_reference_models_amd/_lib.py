@@ -27,6 +27,7 @@ FLAG_LIFELONG = 16
 FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
 FLAG_SINGLE_AGENT = 256
+FLAG_SEQUENTIAL_RESET = 0x20000000
 FLAG_NO_CELL_MAP = 0x40000000
 FLAG_GENERIC_KERNEL = 0x80000000
 

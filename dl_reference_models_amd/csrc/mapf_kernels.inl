@@ -1207,7 +1207,7 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
         pcg_load(g, p.rng + (size_t)env * 6);
         pop = p.n_free[env];
     }
-    bool ok = do_reset && pop > size;
+    bool ok = do_reset && pop > size && !(p.flags & MAPF_FLAG_SEQUENTIAL_RESET);
     const int has = (int)g.has32;
     const int nout = (D - has + 1) >> 1;  // 64-bit outputs consumed; the stream of 32-bit halves is
                                           // [buffered half if has] lo(o1) hi(o1) lo(o2) hi(o2) ...

@@ -118,7 +118,7 @@ hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t
 // the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
 int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) return 0;
-    const uint32_t cfg_flags = c.flags & ~MAPF_FLAG_NO_CELL_MAP;
+    const uint32_t cfg_flags = c.flags & ~(MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_SEQUENTIAL_RESET);
 #define MAPF_MATCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                            \
     if (c.num_agents == N_ && c.sensor_range == SR_ && cfg_flags == (uint32_t)(FLAGS_) &&                             \
         c.deadlock_window_steps == DW_ && c.livelock_window_steps == LW_ && nearby_clamped == NEARBY_ &&           \

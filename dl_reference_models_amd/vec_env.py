@@ -13,6 +13,8 @@ extension keys:
     lanes_per_env   engine tuning knob (0 = auto)
     force_generic_kernel   engine knob: use the runtime-config step kernel even when a compile-time
                     specialisation (BASELINE.json shapes) matches
+    force_sequential_reset   engine knob (tests): in-kernel resets always use the sequential restatement of
+                    ``generate_starts_goals`` instead of the lane-parallel one
 
 All hot-path calls are asynchronous on the current torch stream; outputs are preallocated device
 tensors that are overwritten by the next call (clone them to keep them).
@@ -88,6 +90,8 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_DETERMINISTIC
     if cfg.get("force_pair_walk", False):  # engine knob: all-pairs walk instead of the LDS cell map at N > 16
         f |= L.FLAG_NO_CELL_MAP
+    if cfg.get("force_sequential_reset", False):  # engine knob: in-kernel resets through the sequential sampler only
+        f |= L.FLAG_SEQUENTIAL_RESET
     if cfg.get("force_generic_kernel", False):  # engine knob: skip the compile-time specialised step kernel
         f |= L.FLAG_GENERIC_KERNEL
     return f

@@ -64,6 +64,8 @@ extern "C" {
 #define MAPF_FLAG_LOCK_METRICS 32u        /* enable_lock_metrics [on] */
 #define MAPF_FLAG_DETERMINISTIC 64u       /* deterministic [off]: reset() re-places agents on fixed starts, no RNG */
 #define MAPF_FLAG_SINGLE_AGENT 256u        /* the handle runs the single-agent (CTE) sibling env: use the mapf_cte_* calls */
+#define MAPF_FLAG_SEQUENTIAL_RESET 0x20000000u /* engine knob (tests): in-kernel resets always take the sequential
+                                                 * sampler (otherwise only after a Lemire rejection or when F = 2N) */
 #define MAPF_FLAG_NO_CELL_MAP 0x40000000u   /* engine knob (tests / A-B): never use the LDS cell-map path of wide groups */
 #define MAPF_FLAG_GENERIC_KERNEL 0x80000000u /* engine knob (tests): never pick a compile-time specialised step kernel */
 

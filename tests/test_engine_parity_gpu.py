@@ -230,6 +230,25 @@ def test_state_roundtrip_and_rng_words():
         assert np.array_equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 16, 4), (24, 32, 32, 8), (4, 12, 12, 20)])
+def test_sequential_and_parallel_reset_samplers_agree_with_the_oracle(shape):
+    """The in-kernel reset has two restatements of rng.choice(F, 2N, replace=False): the lane-parallel one (PCG64
+    jump-ahead, all draws at once) and the sequential one it falls back to after a Lemire rejection (probability
+    ~1e-7 per draw, so never seen in a test run).  `force_sequential_reset` takes the fallback on every reset; both
+    must reproduce the oracle across many episode boundaries, RNG words included."""
+    b, h, w, n = shape
+    cfg = {"num_agents": n, "sensor_range": 2, "steps_per_episode": 9, "include_action_mask_in_obs": True}
+    grids = synth_grids(b, h, w, 0.2, n)
+    seeds = list(range(900, 900 + b))
+    acts = np.random.default_rng(12).integers(0, 5, size=(60, b, n)).astype(np.int8)
+    for knob in (False, True):
+        eng = EngineStepper(grids, cfg, seeds=seeds, force_sequential_reset=knob)
+        stats = compare_steppers(eng, OracleStepper(grids, cfg, seeds=seeds), acts)
+        assert stats["episodes"] >= 6 * b
+    if (h, w, n) == (32, 32, 8):
+        assert eng.env.launch_info()["specialized_kernel"] == 1  # the knob does not change the kernel choice
+
+
 @pytest.mark.parametrize("n", [3, 8])
 def test_reset_with_exactly_2n_free_cells_takes_the_sequential_sampler(n):
     """F == 2N: the first Floyd draw has bound 0 and consumes no random number (NumPy returns the offset without
