@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One-off soak (not part of the test suite): the randomized engine-vs-oracle fuzz of
 tests/test_engine_parity_gpu.py with another master seed and many more cases.
-Usage: python tools/soak_fuzz.py [master_seed] [cases]"""
+Usage: python tools/soak_fuzz.py [master_seed] [cases] [fused]
+With `fused`, every case also runs mapf_step_many (observations every step) on a fresh engine and compares it, step
+for step and in its final state, with the single-step engine."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +12,25 @@ from trace_util import EngineStepper, OracleStepper, compare_steppers, synth_gri
 
 master = int(sys.argv[1]) if len(sys.argv) > 1 else 777
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+fused = len(sys.argv) > 3 and sys.argv[3] == "fused"
+
+
+def check_fused(grids, cfg, seeds, extra, acts):
+    import torch
+    one, many = EngineStepper(grids, cfg, seeds=seeds, **extra), EngineStepper(grids, cfg, seeds=seeds, **extra)
+    one.reset(); many.reset()
+    out = many.env.step_many(torch.from_numpy(acts).to(many.env.device), obs_mode=2)
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for t in range(acts.shape[0]):
+        o = one.step(acts[t], auto_reset=True)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            if not np.array_equal(o[k], out[k][t]):
+                raise AssertionError(f"fused {k} differs at step {t}")
+    sa, sb = one.env.get_state(), many.env.get_state()
+    for k in sa:
+        if not np.array_equal(sa[k], sb[k]):
+            raise AssertionError(f"fused final state {k} differs")
+
 rng = np.random.default_rng(master)
 t0 = time.time(); done = 0
 for case in range(cases):
@@ -42,6 +63,8 @@ for case in range(cases):
     acts = rng.choice(5, size=(90, B, N), p=p).astype(np.int8)
     try:
         compare_steppers(EngineStepper(grids, cfg, seeds=seeds, **extra), OracleStepper(grids, cfg, seeds=seeds), acts)
+        if fused:
+            check_fused(grids, cfg, seeds, extra, acts)
     except AssertionError as exc:
         print(f"FAIL case {case}: cfg={cfg} B={B} HxW={H}x{W} density={density} extra={extra}: {exc}", flush=True)
         sys.exit(1)
