@@ -1632,10 +1632,20 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (arr_wave) {  // wave-uniform, rare
             const uint64_t garr = gballot<LPE>(on_goal, lane);
             reassigned = garr != 0;
+            // Everything the respawn reads from global memory that does not depend on an earlier respawn of the same
+            // step is fetched here in one round trip (a wave in which an agent arrives sets the launch's duration):
+            // the stream state, the free-cell count and the row-major ranks of my old cell, my new cell and my goal.
             Pcg g;
             pcg_load(g, p.rng + (size_t)env * 6);
             const int F = p.n_free[env];
             const uint16_t *frank = p.free_rank + (size_t)env * p.HW;
+            const int rankOld = is_agent ? (int)frank[(old >> 8) * W + (old & 255u)] : 0x7FFFFFFF;
+            const int rankCur = is_agent ? (int)frank[(cur >> 8) * W + (cur & 255u)] : 0x7FFFFFFF;
+            int rankGoal = is_agent ? (int)frank[(st.goal >> 8) * W + (st.goal & 255u)] : 0x7FFFFFFF;
+            if (use_map) {  // owner-new ids for the occupancy test below (the full field is ORed in later anyway)
+                if (is_agent) atomicOr(&mapg[map_index(cur, map_w)], (uint32_t)a + 1u);
+                wave_lds_sync();
+            }
             uint64_t u = fold_groups<LPE>(arr_wave);
             while (u) {  // respawns happen in agent order, each sees the state "at time i" (MA-env:554)
                 const int i = (int)__builtin_ctzll(u);
@@ -1644,10 +1654,17 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                 // occupied cells at time i; goals of everybody else (own old goal is released first, MA-env:286-288)
                 const uint32_t P = is_agent ? ((a <= i) ? cur : old) : kIdleCell;
                 const bool Gact = is_agent && a != i;
-                const int rankP = is_agent ? (int)frank[(P >> 8) * W + (P & 255u)] : 0x7FFFFFFF;
-                const int rankG = Gact ? (int)frank[(st.goal >> 8) * W + (st.goal & 255u)] : 0x7FFFFFFF;
+                const int rankP = (a <= i) ? rankCur : rankOld;
+                const int rankG = Gact ? rankGoal : 0x7FFFFFFF;
                 bool dup = false;  // my goal cell is also occupied -> count it once
-                for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(P, q) == st.goal);
+                if (use_map) {
+                    // one map read: index+1 of the agent standing there after (on) / before (oo) the move
+                    const uint32_t mw = is_agent ? mapg[map_index(st.goal, map_w)] : 0u;
+                    const int on = (int)(mw & 127u), oo = (int)((mw >> 7) & 127u);
+                    dup = (on != 0 && on - 1 <= i) || (oo != 0 && oo - 1 > i);
+                } else {
+                    for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(P, q) == st.goal);
+                }
                 dup = dup && Gact;
                 const int overlap = __popcll(gballot<LPE>(dup, lane));
                 const int k = F - N - (N - 1) + overlap;  // candidate_indices.size MA-env:295
@@ -1669,7 +1686,10 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                     y = y2;
                     if (!__any(changed)) break;
                 }
-                if (gact && k > 0 && a == i) st.goal = p.free_cells[(size_t)env * p.HW + y];  // MA-env:301-303
+                if (gact && k > 0 && a == i) {
+                    st.goal = p.free_cells[(size_t)env * p.HW + y];  // MA-env:301-303
+                    rankGoal = y;                                     // the rank of the cell just chosen
+                }
             }
             if (reassigned && a == 0 && env_ok) pcg_store(g, p.rng + (size_t)env * 6);
             if (on_goal) {  // MA-env:547-556
