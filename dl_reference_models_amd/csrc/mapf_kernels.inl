@@ -1983,8 +1983,10 @@ __device__ __forceinline__ Lds with_parity(const Lds &l, int t) {
 }
 
 // One step of the observation wave (wave 1 of a DUAL workgroup).  Everything it needs arrives through LDS: the
-// obstacle rows and the observation table Lds::otab (its own entry carries cur / goal / kObsW* flags).  Barrier protocol per step with observations, identical in both waves: B1 (table complete), then B2
-// only if some env of the workgroup resets (the state wave re-uses table and staging rows for the reset).
+// obstacle rows and the observation table Lds::otab (its own entry carries cur / goal / kObsW* flags).  Barrier
+// protocol per step with observations, identical in both waves: B1 (observation table published), then B2 only if
+// some env of the workgroup resets (the state wave re-uses table and staging rows for the reset observation; its
+// sampling, which only touches the group's scratch, runs before B2).
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
                                               const int ngroups) {
