@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: agent-steps/sec of the env step hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one mapf_step launch over one batch of envs (8192 envs x 32x32 x 8 agents per GPU,
-density 0.40, L = 33, lock metrics on, in-kernel auto-reset), with the actions already resident in
-HBM.  Per-GPU work is fixed as N grows (weak scaling); envs shard with no hot-path collective.
-Rank 0 prints ONE JSON line.  Extra fields: `roofline` (algorithmic bytes / measured kernel time vs
-the 8 TB/s HBM peak) and `cpu_baseline` (the parity-checked C restatement, oracle/, on this box's
-host cores -- a reported baseline, not a target).
+A "step" is one mapf_step launch over one batch of envs (c3: 8192 envs x 32x32 x 8 agents per GPU, density
+0.40, L = 33, lock metrics on, in-kernel auto-reset), with the actions already resident in HBM.  Envs shard
+over the GPUs with no hot-path collective: `--scaling weak` (default) keeps 8192 envs per GPU, `--scaling
+strong` splits a fixed total (c4: 65 536) over the ranks.  Started without torchrun and with --gpus N > 1 the
+script launches one fresh child process per GPU itself (before it touches a GPU) and relays rank 0's line.
+
+The timed region is what an RL loop sees in steady state: episode phases are STAGGERED (env b starts at step
+b mod steps_per_episode), so about 1 % of the envs finish and are re-placed inside EVERY launch; `value` is
+that number.  `value_synchronised` is the same run with all episodes in phase (resets in 1 launch of 100).
+All K timed launches are hipGraph replays (graphs of min(K, --graph-steps) launches plus one for the
+remainder) unless --graph-steps 0.
+
+Rank 0 prints ONE JSON line.  Extra fields: `roofline` (algorithmic bytes / measured kernel time vs the
+8 TB/s HBM peak), `cpu_baseline` (the parity-checked C restatement, oracle/, one thread) and
+`cpu_baseline_all_cores` (one env shard per host thread) -- reported baselines, not targets.
 """
 
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,26 +38,76 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+C4_TOTAL_ENVS = 65536  # BASELINE.json configs[3]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default=None, help="one of dl_reference_models_amd.workloads.WORKLOADS")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the workload's envs per GPU; strong: --total-envs split over the GPUs")
+    ap.add_argument("--total-envs", type=int, default=C4_TOTAL_ENVS, help="strong scaling: envs of the whole job")
     ap.add_argument("--graph-steps", type=int, default=100,
-                    help="steps captured per hipGraph (0 = plain launches)")
+                    help="launches captured per hipGraph (0 = plain launches)")
+    ap.add_argument("--episodes", choices=("staggered", "synchronised", "both"), default="both",
+                    help="episode phases of the timed region(s); `value` is the staggered run unless "
+                         "'synchronised' is asked for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=700)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU baseline leg")
     ap.add_argument("--kernel-samples", type=int, default=200,
-                    help="launches timed one by one with events for the roofline figure")
-    return ap.parse_args()
+                    help="launches timed one by one with events (isolated launch duration)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: ranks share the visible GPUs round-robin and meet over gloo "
+                         "(the line is marked shared_gpu; not a scaling measurement)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(name, env_ids, steps, action_pool):
-    """Time the C oracle (CPU restatement, parity-checked against the reference) single-threaded on a
-    bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------------
+# parent: python bench.py --gpus N without torchrun -> one fresh child per GPU
+# ------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """Start args.gpus worker processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torchrun
+    would export) and relay rank 0's JSON line.  Runs before anything in this process touches a GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle/: test infrastructure, used here only as the reported baseline)
+# ------------------------------------------------------------------------------------------------------
+def host_threads() -> int:
+    """Threads this process may really use: affinity mask, capped by the cgroup cpu quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _oracle_shard(name, env_ids, stagger):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
 
@@ -56,48 +116,102 @@ def cpu_baseline(name, env_ids, steps, action_pool):
     cfg = wl.workload_config(name, env_ids)
     batch = orc.OracleBatch(cfg["grid"], cfg, seeds=cfg["seeds"])
     batch.reset()
-    n = cfg["num_agents"]
-    acts = action_pool[:, : len(env_ids), :]
-    for t in range(5):
-        batch.step(acts[t % acts.shape[0]], auto_reset=True, outputs=True)
-    t0 = time.perf_counter()
+    if stagger:
+        for i, e in zip(env_ids, batch.envs):
+            e.step_count = int(i) % int(cfg["steps_per_episode"])
+    return batch, cfg
+
+
+def _oracle_run(batch, acts, steps):
     for t in range(steps):
         batch.step(acts[t % acts.shape[0]], auto_reset=True, outputs=True)
+
+
+def cpu_baselines(name, env_ids, action_pool, seconds):
+    """The C oracle (CPU restatement, parity-checked against the reference) on a bounded sample of the same
+    workload (same grids, seeds, actions, staggered episode phases): one thread, then one env shard per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    res = {}
+    n_cpu = os.cpu_count()
+    # ---- one thread: a 1024-env sample, step count sized from a short probe
+    ids1 = list(env_ids[:1024])
+    batch, cfg = _oracle_shard(name, ids1, True)
+    n = cfg["num_agents"]
+    acts = action_pool[:, : len(ids1), :]
+    t0 = time.perf_counter()
+    _oracle_run(batch, acts, 10)
+    probe = (time.perf_counter() - t0) / 10
+    steps = int(min(max(seconds / max(probe, 1e-6), 20), 5000))
+    t0 = time.perf_counter()
+    _oracle_run(batch, acts, steps)
     dt = time.perf_counter() - t0
-    return {
-        "value": len(env_ids) * n * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{len(env_ids)} envs x {steps} steps of the same workload, C restatement (oracle/), 1 thread "
-                  f"of {os.cpu_count()} host cpus",
+    res["cpu_baseline"] = {
+        "value": len(ids1) * n * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{len(ids1)} envs x {steps} steps of the same workload (staggered episodes), C restatement "
+                  f"(oracle/), 1 thread of {n_cpu} host cpus",
     }
+    # ---- all cores: one shard of the batch per thread (the C step loop runs outside the GIL)
+    threads = min(host_threads(), 128)
+    per = max(len(env_ids) // threads, 8)
+    shards = []
+    for k in range(threads):
+        ids = list(env_ids[k * per:(k + 1) * per])
+        if ids:
+            shards.append((ids, k * per))
+    made = [(_oracle_shard(name, ids, True)[0], action_pool[:, off:off + len(ids), :]) for ids, off in shards]
+    steps_mt = int(min(max(seconds / max(probe * per / len(ids1), 1e-6), 20), 5000))
+    with ThreadPoolExecutor(len(made)) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda ba: _oracle_run(ba[0], ba[1], steps_mt), made))
+        dt = time.perf_counter() - t0
+    total = sum(b.B for b, _ in made)
+    res["cpu_baseline_all_cores"] = {
+        "value": total * n * steps_mt / dt, "unit": "agent-steps/s", "cores": len(made), "kind": "port",
+        "sample": f"{total} envs x {steps_mt} steps, one shard of {per} envs per thread, {len(made)} threads "
+                  f"(os.cpu_count() = {n_cpu}, usable = {host_threads()})",
+    }
+    return res
 
 
-def main():
-    args = parse_args()
+# ------------------------------------------------------------------------------------------------------
+# worker: one rank = one GPU
+# ------------------------------------------------------------------------------------------------------
+def worker(args) -> int:
     import torch
     import torch.distributed as dist
 
+    from dl_reference_models_amd import _lib as L
     from dl_reference_models_amd import sharding, workloads as wl
-    from dl_reference_models_amd.vec_env import VecReferenceModel
+    from dl_reference_models_amd.vec_env import VecReferenceModel, metrics_from_sums
 
     rank, local_rank, world = sharding.dist_env()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun always go through RCCL, also at world size 1
     if use_dist:
-        dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
     name = args.workload or wl.HEADLINE
-    b_per, h, w, n, density, _ = wl.WORKLOADS[name]
-    env_ids = list(sharding.weak_range(b_per, rank))
+    b_weak, h, w, n, density, _ = wl.WORKLOADS[name]
+    if args.scaling == "strong":
+        env_ids = list(sharding.shard_range(args.total_envs, world, rank))
+        total_envs = args.total_envs
+    else:
+        env_ids = list(sharding.weak_range(b_weak, rank))
+        total_envs = b_weak * world
+    b_per = len(env_ids)
     cfg = wl.workload_config(name, env_ids)
     cfg["device"] = str(device)
     env = VecReferenceModel(cfg)
-    L = env.obs_len
-    env.reset()
+    L_obs = env.obs_len
+    spe = int(cfg["steps_per_episode"])
 
     # actions: uniform over {0..4}, generated once and resident in HBM (inputs, not part of the path)
     pool = max(args.graph_steps, 1) if args.graph_steps else 128
@@ -108,62 +222,85 @@ def main():
     step_raw = env.step_raw
     base, stride = action_pool.data_ptr(), b_per * n
 
-    def run_plain(k0, k):
-        for t in range(k0, k0 + k):
-            rc = step_raw(base + (t % pool) * stride, sptr, 1)
+    def run_plain(k, ptr=sptr):
+        for t in range(k):
+            rc = step_raw(base + (t % pool) * stride, ptr, 1)
             if rc != 0:
                 raise RuntimeError(f"mapf_step failed: {rc}")
 
-    graph = None
-    use_graph = args.graph_steps > 0
-    if use_graph:
-        try:
-            run_plain(0, 3)  # warm the code object before capture
-            torch.cuda.synchronize(device)
-            graph = torch.cuda.CUDAGraph()
-            cap_stream = torch.cuda.Stream(device)
-            with torch.cuda.graph(graph, stream=cap_stream):
-                cptr = torch.cuda.current_stream(device).cuda_stream
-                for t in range(args.graph_steps):
-                    rc = step_raw(base + t * stride, cptr, 1)
-                    if rc != 0:
-                        raise RuntimeError(f"mapf_step failed during capture: {rc}")
-        except Exception as exc:  # graph capture is an optimisation of the launch loop only
-            print(f"[bench] hipGraph capture unavailable ({exc!r}); using plain launches", file=sys.stderr)
-            graph, use_graph = None, False
+    graphs = {}  # launches per graph -> captured graph
 
-    def run_steps(k):
-        if graph is not None:
-            full, rem = divmod(k, args.graph_steps)
-            for _ in range(full):
-                graph.replay()
-            if rem:
-                run_plain(0, rem)
+    def graph_of(k):
+        if k not in graphs:
+            g = torch.cuda.CUDAGraph()
+            cap_stream = torch.cuda.Stream(device)
+            with torch.cuda.graph(g, stream=cap_stream):
+                run_plain(k, torch.cuda.current_stream(device).cuda_stream)
+            graphs[k] = g
+        return graphs[k]
+
+    G = min(args.graph_steps, max(args.steps, 1)) if args.graph_steps > 0 else 0
+
+    def plan(k):
+        """(graph, replays) pairs that make exactly k launches."""
+        if G == 0 or k == 0:
+            return []
+        full, rem = divmod(k, G)
+        return ([(graph_of(G), full)] if full else []) + ([(graph_of(rem), 1)] if rem else [])
+
+    def run_steps(k, pl):
+        if G == 0:
+            run_plain(k)
         else:
-            run_plain(0, k)
+            for g, reps in pl:
+                for _ in range(reps):
+                    g.replay()
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    run_steps(args.warmup)
-    fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run_steps(args.steps)
-    ev1.record(stream)
-    fence()
-    elapsed = time.perf_counter() - t0
-    # HIP events on the launch stream over the timed region: device time per launch (kernel + the
-    # back-to-back boundary; graph replays leave no host gap).  This is the roofline's kernel time.
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    env.poll_error()
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def set_phases(staggered):
+        env.reset()
+        if staggered:  # env with global index i is i mod steps_per_episode steps into its episode
+            c = env.get_state()["counters"]
+            c[:, L.CTR_STEP_COUNT] = np.asarray(env_ids, dtype=np.int64) % spe
+            env.set_state(counters=c)
+
+    def timed_region(staggered):
+        set_phases(staggered)
+        run_plain(3)  # code object resident before any capture
+        torch.cuda.synchronize(device)
+        pl_w, pl_t = plan(args.warmup), plan(args.steps)  # capture happens here, outside the timed region
+        run_steps(args.warmup, pl_w)
+        fence()
+        ep0 = int(env.episode_sums()[L.ACC_EPISODES])
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run_steps(args.steps, pl_t)
+        ev1.record(stream)
+        fence()
+        elapsed = time.perf_counter() - t0
+        # HIP events on the launch stream over the timed region: device time per launch (graph replays leave no
+        # host gap).  This is the roofline's kernel time.
+        kernel_ms = ev0.elapsed_time(ev1) / args.steps
+        env.poll_error()
+        resets = int(env.episode_sums()[L.ACC_EPISODES]) - ep0
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=None if args.share_gpu else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "resets": resets}
+
+    legs = {}
+    if args.episodes in ("staggered", "both"):
+        legs["staggered"] = timed_region(True)
+    if args.episodes in ("synchronised", "both"):
+        legs["synchronised"] = timed_region(False)
+    head = legs["staggered"] if "staggered" in legs else legs["synchronised"]
 
     # ---- secondary: event pairs around single launches (includes ~2 us of event/launch overhead) ----
     samples = []
@@ -178,62 +315,81 @@ def main():
     isolated_launch_ms = float(np.median(per_launch_ms)) if len(per_launch_ms) else None
 
     # off the timed path: episode statistics accumulated on the device, summed over ranks with ONE small
-    # RCCL all-reduce (96 bytes; latency-bound, so one fused buffer)
-    from dl_reference_models_amd.vec_env import metrics_from_sums
-
-    sums = sharding.all_reduce_stats(env.episode_sums().astype(np.float64), device=device if use_dist else None)
-    stats = [float(sums[0])]
+    # all-reduce (96 bytes; latency-bound, so one fused buffer; RCCL on GPUs)
+    sums = sharding.all_reduce_stats(env.episode_sums().astype(np.float64),
+                                     device=device if (use_dist and not args.share_gpu) else None)
     episode_metrics = metrics_from_sums(sums, n, bool(cfg.get("lifelong_mapf", False)))
 
-    agent_steps = b_per * n * args.steps * world
-    bytes_per_launch = wl.algorithmic_bytes_per_env_step(n, L, h, w) * b_per
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    agent_steps = total_envs * n * args.steps
+    bytes_per_launch = wl.algorithmic_bytes_per_env_step(n, L_obs, h, w) * b_per
+    achieved = bytes_per_launch / (head["kernel_ms"] * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and b_per == b_weak:
         try:
             traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
-        except Exception:
+        except (OSError, ValueError):
             traffic = None
 
+    full, rem = divmod(args.steps, G) if G else (0, 0)
+    launch = (f"hipGraph: {full} x {G} launches" + (f" + 1 x {rem}" if rem else "")) if G else "plain launches"
     result = {
-        "metric": "agent-steps/sec at 8192 envs x 8 agents on 32x32 grid" if name == wl.HEADLINE
-        else f"agent-steps/sec ({name})",
-        "value": agent_steps / elapsed,
+        "metric": "agent-steps/sec at 8192 envs x 8 agents on 32x32 grid" if (name == wl.HEADLINE and b_per == b_weak)
+        else f"agent-steps/sec ({name}, {b_per} envs per GPU)",
+        "value": agent_steps / head["elapsed"],
         "unit": "agent-steps/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": 1e3 * head["elapsed"] / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u8/i16 state, f32 observations",
         "data": "synthetic",
         "config": {
-            "workload": name, "envs_per_gpu": b_per, "grid": [h, w], "agents": n, "obstacle_density": density,
-            "obs_floats": L, "sensor_range": cfg["sensor_range"], "steps_per_episode": cfg["steps_per_episode"],
-            "lock_metrics": True, "auto_reset": "in-kernel", "actions": "uniform{0..4}, device-resident",
-            "launch": f"hipGraph x{args.graph_steps}" if graph is not None else "plain launches",
+            "workload": name, "envs_per_gpu": b_per, "total_envs": total_envs, "grid": [h, w], "agents": n,
+            "obstacle_density": density, "obs_floats": L_obs, "sensor_range": cfg["sensor_range"],
+            "steps_per_episode": spe, "lock_metrics": True, "auto_reset": "in-kernel",
+            "episode_phases": "staggered" if "staggered" in legs else "synchronised",
+            "resets_in_timed_region": head["resets"],
+            "actions": "uniform{0..4}, device-resident", "launch": launch,
             "parallelism": f"env-sharded x{world}, no hot-path collective", **env.launch_info(),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "k_step", "kernel_ms": kernel_ms, "isolated_launch_ms": isolated_launch_ms,
+            "kernel": "k_step", "kernel_ms": head["kernel_ms"], "isolated_launch_ms": isolated_launch_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
-        "episodes_finished": float(stats[0]),
+        "episodes_finished": float(sums[L.ACC_EPISODES]),
         "episode_metrics": episode_metrics,
     }
+    if "synchronised" in legs and "staggered" in legs:
+        s = legs["synchronised"]
+        result["value_synchronised"] = agent_steps / s["elapsed"]
+        result["ms_per_step_synchronised"] = 1e3 * s["elapsed"] / args.steps
+        result["resets_in_timed_region_synchronised"] = s["resets"]
+        result["roofline"]["kernel_ms_synchronised"] = s["kernel_ms"]
+        result["roofline"]["frac_synchronised"] = bytes_per_launch / (s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if args.share_gpu:
+        result["shared_gpu"] = True
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(name, env_ids, args.cpu_steps, action_pool_np)
+            result.update(cpu_baselines(name, env_ids, action_pool_np, args.cpu_seconds))
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -86,6 +86,11 @@ class OracleStepper:
             if rng_words is not None:
                 e.set_rng_words(rng_words[b])
 
+    def set_step_counts(self, counts):
+        """Put env b `counts[b]` steps into its episode (staggered episode boundaries)."""
+        for e, c in zip(self.batch.envs, counts):
+            e.step_count = int(c)
+
     def positions(self):
         return np.stack([e.positions.copy() for e in self.batch.envs])
 
@@ -133,6 +138,11 @@ class EngineStepper:
     def set_state(self, positions, goals, rng_words=None):
         self.env.set_state(positions=np.asarray(positions, np.int16), goals=np.asarray(goals, np.int16),
                            starts=np.asarray(positions, np.int16), rng_words=rng_words, clear_episode=True)
+
+    def set_step_counts(self, counts):
+        c = self.env.get_state()["counters"]
+        c[:, 0] = np.asarray(counts, dtype=np.int32)
+        self.env.set_state(counters=c)
 
     def positions(self):
         return self.env.get_state()["positions"]
@@ -193,10 +203,14 @@ def replay_batch_trace(make_stepper, fx: dict, steps: int | None = None, check_r
     return stats
 
 
-def compare_steppers(a, b, actions: np.ndarray, check_state_every: int = 1) -> dict:
-    """Drive two steppers with the same action stream and require identical outputs each step."""
+def compare_steppers(a, b, actions: np.ndarray, check_state_every: int = 1, step_counts=None) -> dict:
+    """Drive two steppers with the same action stream and require identical outputs each step.
+    step_counts: per-env step counter set right after the reset (staggered episode boundaries)."""
     oa, ob = a.reset(), b.reset()
     _eq("reset obs", oa, ob)
+    if step_counts is not None:
+        a.set_step_counts(step_counts)
+        b.set_step_counts(step_counts)
     _eq("reset positions", a.positions(), b.positions())
     _eq("reset goals", a.goals(), b.goals())
     stats = {"steps": 0, "episodes": 0, "deadlock_events": 0.0, "livelock_events": 0.0, "goals": 0.0, "blocking": 0.0}
