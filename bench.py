@@ -83,8 +83,11 @@ def launch_ranks(args) -> int:
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    for line in out.decode().splitlines():  # rank 0's stdout may also carry library chatter (gloo prints there)
+        if line.startswith("{"):
+            print(line, flush=True)
+        elif line.strip():
+            print(line, file=sys.stderr)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print(f"[bench] ranks failed: {bad}", file=sys.stderr)
