@@ -18,6 +18,7 @@ MAPF_ERR_NO_RESPAWN = -3
 MAPF_ERR_CONFIG = -4
 MAPF_ERR_HIP = -5
 MAPF_ERR_STATE = -6
+MAPF_ERR_RNG_GUARD = -7
 
 FLAG_NORMALIZE_GOAL_DELTA = 1
 FLAG_GOAL_DISTANCE = 2
@@ -35,7 +36,7 @@ INFO_ALL = 14
 NUM_COUNTERS = 16
 CTR_STEP_COUNT, CTR_HIST_ROWS, CTR_BLOCKING_COUNT, CTR_GOALS_REACHED_TOTAL = 0, 1, 2, 3
 CTR_DEADLOCK_EVENTS, CTR_LIVELOCK_EVENTS, CTR_DEADLOCK_STEPS, CTR_LIVELOCK_STEPS = 4, 5, 6, 7
-CTR_LOCK_STATE_PREV, CTR_EPISODES_DONE = 8, 9
+CTR_LOCK_STATE_PREV, CTR_EPISODES_DONE, CTR_MAY_FINISH = 8, 9, 10
 
 NUM_EPISODE_ACC = 12
 (ACC_EPISODES, ACC_SUCCESSES, ACC_GOALS_REACHED, ACC_BLOCKING_COUNT, ACC_DEADLOCK_COUNT, ACC_LIVELOCK_COUNT,

@@ -50,6 +50,19 @@ constexpr uint32_t kIdleGoal = 0xFFFDu;
 // each env's rows in LDS, and (when W <= 64 - 2*kRowPad: Io::col_pad = kRowPad) kRowPad sentinel bits at the
 // low end of every row; bits beyond the grid width are ones as well.
 constexpr int kRowPad = 5;  // = MAPF_MAX_SENSOR_RANGE
+// Pre-sampled placement ("slot") of an env's next episode.  In finite mode the env's stream is consumed by reset()
+// alone (generate_starts_goals, MA-env:267-282), so the next rng.choice(F, 2N) can be drawn at any time before the
+// episode ends: sampler workgroups appended to the k_step grid do it in the background (sampler_wave), and the
+// step that ends the episode only installs the placement.  Invariant: slot valid <=> next_sg[env] holds the cells
+// choice() yields from the env's visible stream state, which then sits in vis_rng[env], while Params::rng[env] already
+// holds the state after that draw; slot invalid <=> Params::rng[env] is the visible state.  Consuming the slot is
+// therefore just invalidating it (no copy at the episode boundary); host setters of the stream invalidate it too, and
+// mapf_get_state reports vis_rng for envs whose slot is pending.
+constexpr uint32_t kSlotInvalid = 0xFFFFFFFFu;
+// next_sg lives behind the env scalars in one allocation, so the step kernel reaches it from preloaded arguments
+__device__ __forceinline__ uint32_t *slots_of(int *scal, int B) {
+    return reinterpret_cast<uint32_t *>(scal + (size_t)B * MAPF_NUM_COUNTERS);
+}
 
 // Engine constants, resident in device memory and read through a __restrict__ pointer (scalar loads
 // at the point of use; a by-value struct this size is held in SGPRs for the whole kernel and spills).
@@ -70,6 +83,9 @@ struct Params {
     const int *n_free;           // [B]
     int *err;                    // [4] code, env, agent, value
     int *ep_acc;                 // [B][MAPF_NUM_EPISODE_ACC] lifetime per-env sums over finished episodes
+    uint32_t *next_sg;           // [B][N] pre-sampled placement of the NEXT episode: start | goal << 16, kSlotInvalid = none
+    uint64_t *vis_rng;           // [B][6] while a slot is pending: the env's stream state BEFORE the pre-draw, i.e. what
+                                 // NumPy's bit_generator.state shows at that point (Params::rng already holds the state after)
     unsigned long long *dbg;     // diagnostic build only (-DMAPF_STAMPS): [blocks][16] s_memtime stamps
 };
 
@@ -77,7 +93,8 @@ struct Params {
 // global-address-space pointers; pointers read out of Params are generic and compile to flat_* ops)
 // and the per-launch io tensors
 // IoHead: what the first global loads of a wave need.  The step kernels take these 12 dwords (plus the Params
-// pointer: 14, the preload budget next to the kernarg segment pointer) as individual kernel arguments, because
+// pointer: 14, the preload budget next to the kernarg segment pointer -- a 15th argument is fetched with a scalar load
+// and, if the first addresses depend on it, delays every load of the wave: measured, +0.2 us per step) as individual kernel arguments, because
 // only scalar and pointer arguments can be preloaded into SGPRs at wave launch (a by-value struct cannot): the
 // state loads then leave in the wave's first cycles instead of behind a scalar-load round trip (build.py,
 // -amdgpu-kernarg-preload-count).
@@ -142,7 +159,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         unsigned long long _t;                                                          \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16 + (k)] = _t;       \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + (k)] = _t; \
     } while (0)
 // wave entry time, taken before the first scalar load is waited for; written to slot 15 by MAPF_STAMP_ENTRY_STORE
 #define MAPF_STAMP_ENTRY()                                                              \
@@ -151,7 +168,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
 #define MAPF_STAMP_ENTRY_STORE()                                                        \
     do {                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)blockIdx.x * 16 + 15] = _t_entry;  \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + 15] = _t_entry; \
     } while (0)
 // the same for the observation wave (lane 64 of a two-wave workgroup), slots 10..14
 #define MAPF_STAMP_W1(k)                                                                \
@@ -160,9 +177,19 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         unsigned long long _t;                                                          \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)blockIdx.x * 16 + (k)] = _t;      \
+        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + (k)] = _t; \
+    } while (0)
+// sampler waves (wave 0 of a sampler workgroup): slots 0 entry, 1 need known, 2 draw done, 3 placement stored, 4 = active
+#define MAPF_STAMP_SW(k)                                                                \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long _t;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * 16 + (k)] = _t;            \
     } while (0)
 #else
+#define MAPF_STAMP_SW(k) do { } while (0)
 #define MAPF_STAMP(k) do { } while (0)
 #define MAPF_STAMP_W1(k) do { } while (0)
 #define MAPF_STAMP_ENTRY() do { } while (0)
@@ -177,8 +204,18 @@ constexpr int obs_len_of(int sr, uint32_t flags) {
            ((flags & MAPF_FLAG_BLOCKING_PRESSURE) ? 1 : 0) + ((flags & MAPF_FLAG_ACTION_MASK) ? 5 : 0);
 }
 
+// Sampler workgroups (sampler_wave) of a k_step launch: how many, and where in the grid.  Each of their waves looks
+// after 64 envs; the count is rounded up to a multiple of 8 so that env workgroup b stays on XCD b mod 8 when they lead
+// the grid.  kSamplerFront: a compile-time finite / sampled-placement configuration puts them FIRST (blockIdx < count:
+// they start with the launch and their draw, about as long as an env step, ends with it instead of after it); the
+// runtime-config kernel only knows its mode after a scalar load, so there they trail the env workgroups.
+__host__ __device__ constexpr int sampler_blocks_for(int B, int waves_per_wg) {
+    return ((((B + 63) / 64) + waves_per_wg - 1) / waves_per_wg + 7) & ~7;
+}
+
 struct KRuntime {
     static constexpr bool kFixed = false;
+    static constexpr bool kSamplerFront = false;
     __device__ static __forceinline__ int N(const Params &p) { return p.N; }
     __device__ static __forceinline__ int sr(const Params &p) { return p.sr; }
     __device__ static __forceinline__ int V(const Params &p) { return p.V; }
@@ -195,6 +232,7 @@ struct KRuntime {
 template <int N_, int SR_, uint32_t FLAGS_, int DW_, int LW_, int NEARBY_, int MINN_>
 struct KFixed {
     static constexpr bool kFixed = true;
+    static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0;
     __device__ static __forceinline__ int N(const Params &) { return N_; }
     __device__ static __forceinline__ int sr(const Params &) { return SR_; }
     __device__ static __forceinline__ int V(const Params &) { return 2 * SR_ + 1; }
@@ -378,19 +416,23 @@ __device__ __forceinline__ uint32_t pcg_next32(Pcg &g) {
     g.uinteger = (uint32_t)(n >> 32);
     return (uint32_t)n;
 }
-// random_bounded_uint64(off=0, rng, use_masked=false) for rng < 2^32-1: Lemire with rejection
-__device__ __forceinline__ uint32_t pcg_bounded(Pcg &g, uint32_t rng) {
+// random_bounded_uint64(off=0, rng, use_masked=false) for rng < 2^32-1: Lemire with rejection.
+// The rejection probability per draw is thr / 2^32 < 1e-6 for the bounds of this engine (< 2^13), so 4096 rejections
+// in a row cannot happen (p < 1e-24000); the cap makes termination structural, and if it ever trips `stuck` is set
+// and the caller latches MAPF_ERR_RNG_GUARD instead of continuing on a stream that no longer matches NumPy's.
+__device__ __forceinline__ uint32_t pcg_bounded(Pcg &g, uint32_t rng, bool &stuck) {
     if (rng == 0) return 0;  // no draw
     const uint32_t excl = rng + 1u;
     uint64_t m = (uint64_t)pcg_next32(g) * excl;
     uint32_t left = (uint32_t)m;
     if (left < excl) {
         const uint32_t thr = (0xFFFFFFFFu - rng) % excl;
-        // rejection probability per draw is thr / 2^32 < 1e-6 here; the cap only guards against a hang
-        for (int guard = 0; left < thr && guard < 4096; guard++) {
+        int guard = 0;
+        for (; left < thr && guard < 4096; guard++) {
             m = (uint64_t)pcg_next32(g) * excl;
             left = (uint32_t)m;
         }
+        stuck |= left < thr;
     }
     return (uint32_t)(m >> 32);
 }
@@ -1188,13 +1230,20 @@ __device__ __forceinline__ uint4 static_entry(uint32_t pos, uint32_t goal) {
 //   * Floyd's membership test is a ballot over the lanes that hold the chosen values (no hash set);
 //   * the shuffle swaps run on the LDS copy.
 // Scratch of the group: raw32[4N + 2] | vals[4N] (uint16) | out[2N] (int16).  Returns false for a group that has to
-// take the sequential path; on true, out (at scratch + kSampleOutOff(N)) holds idx and the stream state is stored.
+// take the sequential path; on true, out (at scratch + kSampleOutOff(N)) holds idx and the stream state after the
+// draws is stored to Params::rng[env]; with vis_dst (a pre-drawn placement) the state before them goes to vis_dst[env].
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sample_out_off_i16(int N) { return 2 * (4 * N + 2) + 4 * N; }
 
+struct PcgPre {  // stream state and free-cell count fetched by the caller (background sampler), or nothing
+    bool have;
+    Pcg g;
+    int pop;
+};
 template <int LPE>
 __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, int16_t *scr, int lane, int a, int env,
-                                                             bool env_ok, bool do_reset, int N) {
+                                                             bool env_ok, bool do_reset, int N, uint64_t *vis_dst,
+                                                             const PcgPre &pre = PcgPre{false, {}, 0}) {
     const int size = 2 * N, D = 2 * size - 1;  // bounded draws of one reset
     uint32_t *raw = reinterpret_cast<uint32_t *>(scr);
     uint16_t *vals = reinterpret_cast<uint16_t *>(raw + 4 * N + 2);
@@ -1203,7 +1252,12 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
     g.shi = g.slo = g.ihi = g.ilo = 0;
     g.has32 = g.uinteger = 0;
     int pop = size + 1;
-    if (do_reset) {
+    if (pre.have) {
+        if (do_reset) {
+            g = pre.g;
+            pop = pre.pop;
+        }
+    } else if (do_reset) {
         pcg_load(g, p.rng + (size_t)env * 6);
         pop = p.n_free[env];
     }
@@ -1314,6 +1368,7 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
         f.shi = fin.hi; f.slo = fin.lo; f.ihi = g.ihi; f.ilo = g.ilo;
         f.has32 = (uint32_t)(has + 2 * nout - D);
         f.uinteger = fin_hi32;  // NumPy keeps the last high half in the buffer field even once it has been handed out
+        if (vis_dst) pcg_store(g, vis_dst + (size_t)env * 6);
         pcg_store(f, p.rng + (size_t)env * 6);
     }
     wave_lds_sync();
@@ -1327,55 +1382,70 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, const uint64_t *lrows, uint4 *tab, float *stage,
                                              int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
-                                             bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs,
+                                             bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs, uint32_t &nsg,
                                              bool obs_wave_barrier = false) {
     const int N = K::N(p);
     if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
-        // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False)
-        int16_t *hs = scratch + grp * p.scratch_i16;
-        const int16_t *out = hs + sample_out_off_i16(N);
-        const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, do_reset, N);
-        if (__any(do_reset && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
-            int16_t *outs = hs + p.hash_cap;
-            if (do_reset && !sampled && a == 0) {
-                Pcg g;
-                pcg_load(g, p.rng + (size_t)env * 6);
-                const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
-                for (int k = 0; k < hash_cap; k++) hs[k] = -1;
-                for (int j = pop - size; j < pop; j++) {  // Floyd
-                    int val = (int)pcg_bounded(g, (uint32_t)j);
-                    int loc = val & mask;
-                    // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
-                    // probe counters only make termination structural
-                    for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
-                    if (hs[loc] == -1) {
-                        hs[loc] = (int16_t)val;
-                        outs[j - pop + size] = (int16_t)val;
-                    } else {
-                        loc = j & mask;
-                        for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
-                        hs[loc] = (int16_t)j;
-                        outs[j - pop + size] = (int16_t)j;
+        // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False).  A pre-drawn placement (see
+        // kSlotInvalid) IS that draw; otherwise it is made here.
+        const bool slot_ok = do_reset && gballot<LPE>(is_agent && nsg == kSlotInvalid, lane) == 0;
+        const bool draw = do_reset && !slot_ok;
+        if (__any(draw)) {
+            int16_t *hs = scratch + grp * p.scratch_i16;
+            const int16_t *out = hs + sample_out_off_i16(N);
+            const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, nullptr);
+            if (__any(draw && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
+                int16_t *outs = hs + p.hash_cap;
+                if (draw && !sampled && a == 0) {
+                    Pcg g;
+                    pcg_load(g, p.rng + (size_t)env * 6);
+                    const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
+                    bool stuck = false;
+                    for (int k = 0; k < hash_cap; k++) hs[k] = -1;
+                    for (int j = pop - size; j < pop; j++) {  // Floyd
+                        int val = (int)pcg_bounded(g, (uint32_t)j, stuck);
+                        int loc = val & mask;
+                        // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
+                        // probe counters only make termination structural
+                        for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                        if (hs[loc] == -1) {
+                            hs[loc] = (int16_t)val;
+                            outs[j - pop + size] = (int16_t)val;
+                        } else {
+                            loc = j & mask;
+                            for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                            hs[loc] = (int16_t)j;
+                            outs[j - pop + size] = (int16_t)j;
+                        }
                     }
+                    for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
+                        int j = (int)pcg_bounded(g, (uint32_t)i, stuck);
+                        int16_t t = outs[j];
+                        outs[j] = outs[i];
+                        outs[i] = t;
+                    }
+                    if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, 0, 0);
+                    if (env_ok) pcg_store(g, p.rng + (size_t)env * 6);
                 }
-                for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
-                    int j = (int)pcg_bounded(g, (uint32_t)i);
-                    int16_t t = outs[j];
-                    outs[j] = outs[i];
-                    outs[i] = t;
-                }
-                if (env_ok) pcg_store(g, p.rng + (size_t)env * 6);
+                wave_lds_sync();
+                if (draw && !sampled) out = outs;
+            }
+            if (draw && is_agent) {
+                const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+                const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+                st.start = fc[min(max((int)out[a], 0), top)];
+                st.goal = fc[min(max((int)out[N + a], 0), top)];
             }
             wave_lds_sync();
-            if (do_reset && !sampled) out = outs;
         }
-        if (do_reset && is_agent) {
-            const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
-            const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
-            st.start = fc[min(max((int)out[a], 0), top)];
-            st.goal = fc[min(max((int)out[N + a], 0), top)];
+        if (__any(slot_ok)) {
+            if (slot_ok && is_agent) {
+                st.start = nsg & 0xFFFFu;
+                st.goal = nsg >> 16;
+                slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;  // consumed: Params::rng is the visible state again
+            }
         }
-        wave_lds_sync();
+        if (do_reset) nsg = kSlotInvalid;
     }
     if (do_reset) {
         st.pos = st.start;  // MA-env:279 / :453
@@ -1391,6 +1461,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         sc[MAPF_CTR_DEADLOCK_STEPS] = 0;
         sc[MAPF_CTR_LIVELOCK_STEPS] = 0;
         sc[MAPF_CTR_LOCK_STATE_PREV] = 0;
+        sc[MAPF_CTR_MAY_FINISH] = 1;  // conservative; the next step computes the real hint
     }
     // Two-wave step kernel: the sampling above only touched the group's scratch, so it ran beside the observation wave;
     // pair table and staging rows are that wave's until it has passed B2.
@@ -1461,10 +1532,11 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     int sc[12];
     load_scal(io.scal, env, sc);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
+    uint32_t nsg = p.next_sg[(size_t)env * N + min(a, N - 1)];
     wave_lds_sync();
 
     reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
-                             io.obs != nullptr);
+                             io.obs != nullptr, nsg);
     if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     if (do_reset) {
         if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
@@ -1517,14 +1589,16 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // (c3: 1024 workgroups on 1024 SIMDs) a step is bound by one wave's dependent-instruction latency, not by
 // bandwidth or issue slots; the split takes the observation (about a third of the instructions) off that path.
 constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSelShift = 3u, kObsWFast = 32u,
-                   kObsWReset = 64u;
+                   kObsWReset = 64u,       // the state wave builds this group's reset observation itself, after B2
+                   kObsWResetFast = 128u;  // the observation wave builds it (second pass) from entry word z
 
 // rec0 != nullptr (single-step kernel, full wave): the wave's 64 agent records and the envs' counters are stored
 // from inside the body, as soon as they are final, unless an env of the wave resets in this launch; returns
 // whether that happened.
 template <class K, int LPE, int MW, bool FAST, bool DUAL>
 __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                          const int ngroups, int act, Lane &st, int *sc, AgentRec *rec0 = nullptr) {
+                                          const int ngroups, int act, Lane &st, int *sc, uint32_t &nsg,
+                                          AgentRec *rec0 = nullptr, const bool nsg_lazy = false) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const bool env_ok = FAST ? true : (grp < ngroups);
@@ -1608,15 +1682,55 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     }
     const bool done = env_ok && !errored && (term | trunc);
     const bool do_reset = done && io.auto_reset;
+    // How a finished env gets its next episode:
+    //   fast  the placement is known already -- a pre-drawn slot (kSlotInvalid) or the fixed starts of deterministic
+    //         mode -- so the reset is a register image and the OBSERVATION WAVE builds the reset observation, instead
+    //         of the terminal one when nobody asked for that, else in a second pass; this wave never waits for it;
+    //   slow  reset_groups() at the end of the body: draws the placement, builds the observation after B2.
+    const bool deterministic = (flags & MAPF_FLAG_DETERMINISTIC) != 0;
+    const bool want_any_obs = io.obs || io.final_obs;
+    const bool obs_wave = DUAL && want_any_obs;  // the other wave works this step (workgroup-uniform)
+    // the placement a fast reset installs, start | goal << 16 (deterministic: reset() keeps the goals, MA-env:452-455)
+    auto reset_placement = [&]() -> uint32_t {
+        if (!is_agent) return kIdleCell | (kIdleGoal << 16);
+        return deterministic ? ((st.start & 0xFFFFu) | (st.goal << 16)) : nsg;
+    };
     // which tensor a group's observation goes to: 0 io.obs, 1 io.final_obs (terminal observation of an env that is
-    // reset right away), 2 nowhere
-    const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-    const bool obs_wave = DUAL && (io.obs || io.final_obs);  // the other wave works this step (workgroup-uniform)
+    // reset right away), 2 nowhere;  obs_w0: the kObsW* flags of this lane's table entry
+    int sel = (!env_ok || errored) ? 2 : (io.obs ? 0 : 2);
+    uint32_t obs_w0 = (is_agent ? kObsWAgent : 0u) | (pressure_prev ? kObsWPressure : 0u) | (FAST ? kObsWFast : 0u);
+    bool fast_reset = false, slow_reset = false, subst = false;
+    // Everything about episode ends sits behind ONE wave-uniform branch: a step in which no env of the wave finishes
+    // (the common case) pays a ballot and a scalar branch for it.
+    if (__builtin_expect(__any(do_reset), 0)) {
+        if (nsg_lazy && !deterministic && !lifelong)  // (A/B: the slot is only fetched when an env of the wave finishes)
+            nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
+        bool slot_ok = deterministic;
+        if (!deterministic && !lifelong) slot_ok = gballot<LPE>(is_agent && nsg == kSlotInvalid, lane) == 0;
+#ifdef MAPF_NO_FAST_RESET  // (A/B builds)
+        slot_ok = false;
+#endif
+        fast_reset = do_reset && !use_map && slot_ok && (obs_wave || !want_any_obs);
+        slow_reset = do_reset && !fast_reset;
+        subst = fast_reset && io.final_obs == nullptr;  // reset observation in place of the terminal one
+        if (do_reset) sel = io.final_obs ? 1 : ((subst && io.obs) ? 0 : 2);
+        if (subst) obs_w0 = (obs_w0 & ~kObsWPressure) | kObsWFinal;
+        obs_w0 |= (slow_reset ? kObsWReset : 0u) | ((fast_reset && !subst) ? kObsWResetFast : 0u);
+    }
+    obs_w0 |= (uint32_t)sel << kObsWSelShift;
     uint4 *otabg = l.otab + grp * LPE;
-    const uint32_t obs_w0 = (is_agent ? kObsWAgent : 0u) | (pressure_prev ? kObsWPressure : 0u) |
-                            ((uint32_t)sel << kObsWSelShift) | (FAST ? kObsWFast : 0u) | (do_reset ? kObsWReset : 0u);
+    // entry the observation wave reads: x old | new << 16, y goal, z reset placement, w kObsW* flags
+    auto obs_entry = [&](bool all_final) -> uint4 {
+        uint4 e = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (all_final ? kObsWFinal : 0u));
+        if (__builtin_expect(__any(fast_reset), 0)) {
+            const uint32_t rs = reset_placement(), rs_pos = rs & 0xFFFFu;
+            e.z = rs;
+            if (subst) e = make_uint4(rs_pos | (rs_pos << 16), rs >> 16, rs, obs_w0);
+        }
+        return e;
+    };
     if (obs_wave && !lifelong && !use_map) {  // finite episodes: goals are fixed, the observation only waited for the moves
-        otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0);
+        otabg[a] = obs_entry(false);
         wg_sync();  // B1
     }
 
@@ -1673,7 +1787,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                     if (k <= 0) {
                         if (a == i) raise_error(p, MAPF_ERR_NO_RESPAWN, env, i, k);
                     } else {
-                        r = pcg_bounded(g, (uint32_t)(k - 1));  // rng.integers(k) MA-env:300
+                        bool stuck = false;
+                        r = pcg_bounded(g, (uint32_t)(k - 1), stuck);  // rng.integers(k) MA-env:300
+                        if (stuck && a == i) raise_error(p, MAPF_ERR_RNG_GUARD, env, i, k);
                     }
                 }
                 // r-th candidate in row-major order = free-rank y with y = r + #{excluded ranks <= y}
@@ -1753,6 +1869,12 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         delta = d_old - dist;
         sc[MAPF_CTR_HIST_ROWS] = t + 1;
     }
+    // hint for the background sampler (sampler_wave): may this episode end in the NEXT step?  Only then could the
+    // env's stream be consumed by a reset while the sampler draws from it.  Finite episodes end when every agent
+    // stands on its goal -- impossible next step while some agent is two or more cells away -- or at the step limit.
+    if (!lifelong)
+        sc[MAPF_CTR_MAY_FINISH] = (gballot<LPE>(is_agent && dist > 1, lane) == 0 ||
+                                   sc[MAPF_CTR_STEP_COUNT] + 1 >= io.steps_per_episode) ? 1 : 0;
 
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
     // neighbour / blocking / coincidence pass
@@ -1762,7 +1884,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     // without observations)
     const bool emit_here = !obs_wave && (io.obs || io.final_obs);
     if (obs_wave && lifelong && !use_map) {  // respawned goals are part of the observation: publish after the goal logic
-        otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (reassigned ? kObsWFinal : 0u));
+        otabg[a] = obs_entry(reassigned);
         wg_sync();  // B1
     }
     if (use_map) {
@@ -1776,7 +1898,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
             if (!reached) atomicOr(&mapg[(tr + kRowPad) * map_w + tc + kRowPad], 1u << 21);
         }
         if (obs_wave) {  // the observation wave reads its window from the map: release it when the map is complete
-            otabg[a] = make_uint4(old | (cur << 16), st.goal & 0xFFFFu, 0u, obs_w0 | (reassigned ? kObsWFinal : 0u));
+            otabg[a] = obs_entry(reassigned);
             wg_sync();  // B1
         } else {
             wave_lds_sync();
@@ -1810,7 +1932,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     //      wave does this, concurrently with everything below) --------------------------------------------
     if (emit_here) {
         wave_lds_sync();
-        if (FAST && !__any(do_reset)) {
+        if (FAST && !__any(do_reset)) {  // (no fast resets on this path: they need the observation wave)
             if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
         } else {
             flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, sel);
@@ -1839,10 +1961,22 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (io.truncated) io.truncated[env] = (uint8_t)trunc;
     }
     bool records_stored = false;
-    if (FAST && rec0 != nullptr && !__any(do_reset)) {
+    if (FAST && rec0 != nullptr && !__any(slow_reset)) {
         st.pos = cur;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
-        store_lanes_coalesced(rec0, l.xpose, lane, st);
+        Lane img = st;
+        if (__builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+            const uint32_t rs = reset_placement();
+            img.start = fast_reset ? (rs & 0xFFFFu) : st.start;
+            img.goal = fast_reset ? (rs >> 16) : st.goal;
+            img.pos = fast_reset ? img.start : st.pos;
+            img.flags = fast_reset ? 0u : st.flags;
+            img.moved = fast_reset ? 0ull : st.moved;
+            img.failed = fast_reset ? 0ull : st.failed;
+            img.progress = fast_reset ? 0ull : st.progress;
+            img.dist = fast_reset ? make_uint4(0, 0, 0, 0) : st.dist;
+        }
+        store_lanes_coalesced(rec0, l.xpose, lane, img);
         records_stored = true;
     }
 
@@ -1907,6 +2041,10 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                     xs[grp * 3] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
                     xs[grp * 3 + 1] = make_uint4(sc[4], sc[5], sc[6], sc[7]);
                     xs[grp * 3 + 2] = make_uint4(sc[8], sc[9], sc[10], sc[11]);
+                    if (fast_reset) {  // a re-placed env stores the counters reset() leaves
+                        xs[grp * 3] = xs[grp * 3 + 1] = make_uint4(0, 0, 0, 0);
+                        xs[grp * 3 + 2] = make_uint4(0, sc[MAPF_CTR_EPISODES_DONE] + 1, 1, sc[11]);
+                    }
                 }
             }
             wave_lds_sync();
@@ -1935,6 +2073,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         st.progress = h_progress;
         st.dist = h_dist;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (pressure_prev ? kFlagPressure : 0);
+        sc[MAPF_CTR_MAY_FINISH] = 1;  // agents before the bad one did move: the hint of the previous step is stale
     } else {
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
     }
@@ -1964,12 +2103,32 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
 
     // ---- auto-reset of finished envs (reference harness loop scripts/benchmark_multi_agent_env.py:89-95:
     //      reset() right after a done step) ------------------------------------------------------------
-    if (__any(do_reset)) {
-        if (do_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
+    if (__builtin_expect(__any(fast_reset), 0)) {  // placement known: reset() is a register image (MA-env:440-455), the observation wave
+                              // has (or is building) the reset observation
+        if (fast_reset) {
+            const uint32_t rs = reset_placement();
+            st.start = rs & 0xFFFFu;
+            st.goal = rs >> 16;
+            st.pos = st.start;
+            st.flags = 0;
+            st.moved = st.failed = st.progress = 0;
+            st.dist = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k <= MAPF_CTR_LOCK_STATE_PREV; k++) sc[k] = 0;
+            sc[MAPF_CTR_EPISODES_DONE] += 1;
+            sc[MAPF_CTR_MAY_FINISH] = 1;
+        }
+        if (fast_reset && !deterministic) {  // the slot is consumed (Params::rng already is the stream after its draw)
+            if (is_agent) slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;
+            nsg = kSlotInvalid;
+        }
+    }
+    if (__builtin_expect(__any(slow_reset), 0)) {
+        if (slow_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
         wave_lds_sync();
-        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st,
-                                 sc, io.obs != nullptr, obs_wave);  // B2 inside: after the sampling, before the observation
-        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
+        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, slow_reset,
+                                 st, sc, io.obs != nullptr, nsg, obs_wave);  // B2 inside: after the draw, before the observation
+        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, slow_reset ? 0 : 2);
     }
     return records_stored;
 }
@@ -2013,18 +2172,111 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
     }
     wave_lds_sync();
     MAPF_STAMP_W1(12);
-    const bool any_reset = __any((w & kObsWReset) != 0);
-    if (__all((w & kObsWFast) != 0) && !any_reset) {
+    const bool any_slow = __any((w & kObsWReset) != 0);
+    const bool any_fast = __any((w & kObsWResetFast) != 0);
+    if (__all((w & kObsWFast) != 0) && !any_slow && !any_fast) {
         if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
     } else {
         flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, (int)((w >> kObsWSelShift) & 3u));
     }
     MAPF_STAMP_W1(13);
+    if (any_fast) {
+        // Second pass: groups that were re-placed in this step and whose terminal observation was wanted (it just
+        // went to final_obs).  Their table entries are rewritten to the reset state (everybody on its start, the
+        // new goals: entry word z) and the reset observation goes to io.obs.
+        const bool fr = (w & kObsWResetFast) != 0;
+        const uint32_t rpos = ent.z & 0xFFFFu, rgoal = ent.z >> 16;
+        uint4 *mine = l.otab + grp * LPE;
+        wave_lds_sync();
+        if (fr) mine[a] = make_uint4(rpos | (rpos << 16), rgoal, ent.z, w);
+        wave_lds_sync();
+        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent && fr, a, rpos, rgoal, true, false, 0, po);
+        wave_lds_sync();
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, fr ? 0 : 2);
+    }
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MAPF_STAMP_W1(14);
 #endif
-    if (any_reset) wg_sync();  // B2
+    if (any_slow) wg_sync();  // B2
+}
+
+// ------------------------------------------------------------------------------------------------
+// Background sampler: workgroups appended to the k_step grid (blockIdx >= number of env workgroups) whose waves
+// pre-draw the NEXT episode's placement of envs that have none (kSlotInvalid), so that the step which ends the episode
+// finds it ready (step_body: fast reset).  Lane i of sampler wave sw looks at env 64*sw + i; envs in need are then
+// handled G at a time by the wave's lane groups with the same lane-parallel restatement of rng.choice(F, 2N) the
+// inline reset uses, writing the slot (next_sg, vis_rng, and the advanced stream) instead of the env's state.
+// No race with the env's own workgroup: an env is only touched when its MAY_FINISH hint (written by the previous
+// step) is clear, i.e. when this launch cannot reset it, so nobody else reads or writes its stream or slot now.
+// ------------------------------------------------------------------------------------------------
+template <class K, int LPE>
+__device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, int16_t *scratch, const int sw, const int lane,
+                                             const int sw_row) {
+    (void)sw_row;
+    constexpr int G = 64 / LPE;
+    const int N = K::N(p);
+    const int grp = lane / LPE, a = lane % LPE;
+    MAPF_STAMP_SW(0);
+    const int e_l = sw * 64 + lane;
+    const bool in = e_l < io.B;
+    const int e_c = in ? e_l : io.B - 1;
+    // One round trip fetches everything a draw needs, for the env each lane looks at: slot word, hint, stream state
+    // and free-cell count (3 KiB per wave whether or not anything is to be done; a dependent second trip would sit on
+    // the one path of the launch that has no slack).
+    const uint32_t slot0 = slots_of(io.scal, io.B)[(size_t)e_c * N];
+    const int hint = io.scal[(size_t)e_c * kScalInts + MAPF_CTR_MAY_FINISH];
+    const uint4 *rw = reinterpret_cast<const uint4 *>(p.rng + (size_t)e_c * 6);
+    const uint4 r0 = rw[0], r1 = rw[1], r2 = rw[2];
+    const int pop_l = p.n_free[e_c];
+    // (bitwise: all loads are in flight before any value is looked at)
+    uint64_t need = __ballot((int)in & (int)(slot0 == kSlotInvalid) & (int)(hint == 0));
+    MAPF_STAMP_SW(1);
+#ifdef MAPF_STAMPS
+    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * 16 + 4] = need ? 1 : 0;
+#endif
+    // ONE round per launch: the first G envs in need are served, the others in a later launch (an episode that ends
+    // before its turn draws inline, like any env without a slot).  A wave's work is thereby bounded by one draw, which
+    // hides under the step of the env workgroups even when every env of the batch finished in the same step.
+    if (need) {
+        int pick = -1;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (need) {
+                const int bit = (int)__builtin_ctzll(need);
+                need &= need - 1;
+                pick = (grp == g) ? bit : pick;
+            }
+        }
+        const bool act = pick >= 0;
+        const int env = act ? sw * 64 + pick : io.B - 1;
+        const int src = act ? pick : lane;  // the lane that fetched the picked env's stream
+        PcgPre pre;
+        pre.have = true;
+        pre.g.shi = (uint64_t)(uint32_t)__shfl((int)r0.x, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r0.y, src, 64) << 32);
+        pre.g.slo = (uint64_t)(uint32_t)__shfl((int)r0.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r0.w, src, 64) << 32);
+        pre.g.ihi = (uint64_t)(uint32_t)__shfl((int)r1.x, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r1.y, src, 64) << 32);
+        pre.g.ilo = (uint64_t)(uint32_t)__shfl((int)r1.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r1.w, src, 64) << 32);
+        pre.g.has32 = (uint32_t)__shfl((int)r2.x, src, 64);
+        pre.g.uinteger = (uint32_t)__shfl((int)r2.z, src, 64);
+        pre.pop = __shfl(pop_l, src, 64);
+        int16_t *hs = scratch + grp * p.scratch_i16;
+        const bool ok = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, act, act, N, p.vis_rng, pre);
+        MAPF_STAMP_SW(2);
+        if (act && ok && a < N) {
+            const int16_t *out = hs + sample_out_off_i16(N);
+            const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+            const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+            const uint32_t s = fc[min(max((int)out[a], 0), top)];
+            const uint32_t g = fc[min(max((int)out[N + a], 0), top)];
+            slots_of(io.scal, io.B)[(size_t)env * N + a] = s | (g << 16);
+        }
+        wave_lds_sync();
+#ifdef MAPF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MAPF_STAMP_SW(3);
+    }
 }
 
 // Workgroup shape of the step kernels: kStepWaves waves of 64 lanes.  Wave 0 is the state wave, wave 1 (when
@@ -2040,8 +2292,11 @@ constexpr bool dual_many_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
 constexpr int step_threads(int lpe) { return dual_for(lpe) ? 128 : 64; }
 constexpr int many_threads(int lpe) { return dual_many_for(lpe) ? 128 : 64; }
 
+// Second launch-bound = minimum waves per SIMD the register budget must allow.  Wide groups: every SIMD has to hold a
+// state wave and an observation wave (c5 launches exactly two waves per SIMD; past 256 registers half of the workgroups
+// wait for a second round: 7.3 -> 11.4 us per step, measured).
 template <class K, int LPE, int MW>
-__global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+__global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
                                                             const IoTail tail) {
     MAPF_STAMP_ENTRY();
     const Params &p = *pp;
@@ -2051,10 +2306,33 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int wv = kDual ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
-    const int env0 = blockIdx.x * G;
+    constexpr int kWavesPerWg = kDual ? 2 : 1;
+    const int main_blocks = (io.B + G - 1) / G;
+    // leading sampler workgroups shift the env workgroups (sampler_blocks_for: a function of the preloaded B alone)
+#ifdef MAPF_NO_SAMPLER_WG  // (A/B builds: the host launches no sampler workgroups)
+    const int lead = 0;
+#else
+    const int lead = K::kSamplerFront ? sampler_blocks_for(io.B, kWavesPerWg) : 0;
+#endif
+    const int env0 = ((int)blockIdx.x - lead) * G;
     const int ngroups = min(G, io.B - env0);
     const int N = K::N(p);
 
+    // (unlikely: keeps the env workgroups' path the fall-through -- as the first block of the kernel the sampler code
+    // pushed their entry 5 KB down and their first scalar loads behind a taken branch: +0.2 us per step)
+    if (__builtin_expect(env0 < 0 || env0 >= io.B, 0)) {  // a sampler workgroup (the host adds them in finite mode
+                                                          // with sampled placements)
+        const Lds l = carve_lds(io, lds_raw);
+        const int si = K::kSamplerFront ? (int)blockIdx.x : (int)blockIdx.x - main_blocks;
+        // two independent sampler waves per workgroup; the second borrows the (unused here) table region as scratch
+        sampler_wave<K, LPE>(p, io, wv == 0 ? l.scratch : reinterpret_cast<int16_t *>(l.tab), si * kWavesPerWg + wv, lane,
+                             main_blocks + si);
+        return;
+    }
+
+#ifdef MAPF_MAIN_PRIO  // (A/B) env workgroups issue ahead of a sampler wave that shares their SIMD
+    __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
+#endif
     // Both waves issue their global loads from the preloaded arguments alone, and only then wait for the scalar
     // loads (rest of the arguments, Params) in one batch.
     if (kDual && wv == 1) {
@@ -2078,11 +2356,17 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     const bool is_agent = env_ok && a < N;
 
     // ---- loads: agent record, action, env scalars (and the obstacle rows in the single-wave build)
+#ifndef MAPF_NSG_MODE
+#define MAPF_NSG_MODE 0  // A/B: 0 slot dword fetched with the state (after it), 1 only when an env finishes, 2 before the state
+#endif
+    uint32_t nsg = kSlotInvalid;  // pre-drawn placement of the next episode
+    if (MAPF_NSG_MODE == 2) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     LaneRaw raw;
     lane_issue(io.agents + (size_t)env * N + min(a, N - 1), raw);
     int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
     int sc[12];
     load_scal(io.scal, env, sc);
+    if (MAPF_NSG_MODE == 0) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     RowRegs rr;
     if (!kDual) rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
     __builtin_amdgcn_sched_barrier(0);  // nothing below may be hoisted between the loads
@@ -2106,10 +2390,10 @@ __global__ __launch_bounds__(step_threads(LPE)) void k_step(const Params *__rest
     MAPF_STAMP(1);
     bool records_stored = false;
     if (full && !__any(act < 0 || act > 4))
-        records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc,
-                                                            io.agents + (size_t)env0 * N);
+        records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg,
+                                                            io.agents + (size_t)env0 * N, MAPF_NSG_MODE == 1);
     else
-        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc);
+        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, MAPF_NSG_MODE == 1);
     if (!records_stored) {  // otherwise records and counters left from inside the body
         if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, st);
         else if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
@@ -2177,6 +2461,8 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
     load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
+    // a pre-drawn placement serves the env's first reset of this launch; later ones draw inline (no sampler here)
+    uint32_t nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     if (kDual) {
         wg_sync();  // B0
     } else {
@@ -2201,9 +2487,9 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
         int act = (int)io.actions[(size_t)t * BN + (size_t)env * N + min(a, N - 1)];
         act = (full || is_agent) ? act : 0;
         if (full && !__any(act < 0 || act > 4))
-            step_body<K, LPE, MW, true, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
+            step_body<K, LPE, MW, true, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc, nsg);
         else
-            step_body<K, LPE, MW, false, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc);
+            step_body<K, LPE, MW, false, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc, nsg);
         wave_lds_sync();  // this wave's staging / table regions are reused by the next step
     }
     if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
@@ -2315,11 +2601,11 @@ __device__ __forceinline__ void cte_sample_starts_goals(const Params &p, const i
         pcg_load(g, p.rng + (size_t)env * 6);
         const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
         const uint32_t top = (uint32_t)(p.n_free[env] - 1);
-        bool gave_up = false;
+        bool gave_up = false, stuck = false;
         for (int i = 0; i < N && !gave_up; i++) {
             int guard = 0;
             for (;; guard++) {
-                const uint16_t cell = fc[pcg_bounded(g, top)];
+                const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
                 bool clash = false;
                 for (int j = 0; j < i; j++) clash |= starts[j] == cell;
                 if (!clash) { starts[i] = cell; break; }
@@ -2329,7 +2615,7 @@ __device__ __forceinline__ void cte_sample_starts_goals(const Params &p, const i
         for (int i = 0; i < N && !gave_up; i++) {
             int guard = 0;
             for (;; guard++) {
-                const uint16_t cell = fc[pcg_bounded(g, top)];
+                const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
                 bool clash = false;
                 for (int j = 0; j < i; j++) clash |= goals[j] == cell;
                 for (int j = 0; j < N; j++) clash |= starts[j] == cell;
@@ -2338,6 +2624,7 @@ __device__ __forceinline__ void cte_sample_starts_goals(const Params &p, const i
             }
         }
         if (gave_up) raise_error(p, MAPF_ERR_FEW_FREE, env, 0, 0);
+        if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, 0, 0);
         pcg_store(g, p.rng + (size_t)env * 6);
     }
     wave_lds_sync();

@@ -59,6 +59,7 @@ struct mapf_engine {
     int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
     double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
     int blocks = 0;
+    int sampler_blocks = 0;  // k_step only: workgroups appended to the grid that pre-draw next-episode placements
     int lds_bytes = 0;
     bool grids_set = false;
     std::string err;
@@ -73,6 +74,7 @@ struct mapf_engine {
     int *d_n_free = nullptr;
     int *d_err = nullptr;
     int *d_ep_acc = nullptr;
+    uint64_t *d_vis_rng = nullptr;  // [B][6] visible stream state of envs whose placement slot is pending (Params::vis_rng)
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
 };
@@ -91,6 +93,43 @@ int fail(mapf_engine *e, int code, const std::string &msg) {
             return fail((e), MAPF_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));            \
     } while (0)
 
+// Makes the handle's GPU current for the duration of an ABI call and puts the caller's device back on every exit
+// path: a process that holds envs on several GPUs (or whose torch current device differs) must not find its
+// thread's device switched by a step() or by a destructor run from the garbage collector.
+struct DeviceScope {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceScope(int dev) {
+        status = hipGetDevice(&prev);
+        if (status != hipSuccess) { prev = -1; return; }
+        if (prev != dev) status = hipSetDevice(dev); else prev = -1;  // hot path: nothing to do, nothing to undo
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define ON_DEVICE(e)                                                                                       \
+    DeviceScope _dev_scope((e)->cfg.device);                                                               \
+    if (_dev_scope.status != hipSuccess)                                                                   \
+        return fail((e), MAPF_ERR_HIP, std::string("selecting the handle's device: ") + hipGetErrorString(_dev_scope.status))
+
+#define LAUNCH_TRY(e, call)                                                                               \
+    do {                                                                                                  \
+        hipError_t _s = (call);                                                                           \
+        if (_s != hipSuccess)                                                                             \
+            return fail((e), MAPF_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(_s)); \
+    } while (0)
+
+// Status of the launch just made.  hipGetLastError() also returns (and clears) an error some earlier, unrelated call
+// left on this thread (torch, RCCL, an event query), so stale state is dropped right before the launch and only what
+// the launch itself raised is reported.
+#define LAUNCH_CHECKED(...)                          \
+    do {                                             \
+        (void)hipGetLastError();                     \
+        hipLaunchKernelGGL(__VA_ARGS__);             \
+        return hipGetLastError();                    \
+    } while (0)
+
 int pick_lpe(int n) {
     int l = 4;
     while (l < n) l <<= 1;
@@ -106,13 +145,11 @@ enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP)
-        hipLaunchKernelGGL((k_step<KRuntime, LPE, MW>), dim3(e->blocks), dim3(step_threads(LPE)), e->lds_bytes, s, e->d_params,
-                           IO_HEAD_ARGS(io));
-    else if (kind == KIND_RESET)
-        hipLaunchKernelGGL((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
-    else
-        hipLaunchKernelGGL((k_observe<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
-    return hipGetLastError();
+        LAUNCH_CHECKED((k_step<KRuntime, LPE, MW>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
+                       e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
+    if (kind == KIND_RESET)
+        LAUNCH_CHECKED((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+    LAUNCH_CHECKED((k_observe<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
 }
 
 // the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
@@ -133,9 +170,9 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((k_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),        \
-                           dim3(e->blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io)); \
-        return hipGetLastError();
+        LAUNCH_CHECKED((k_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),            \
+                       dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params,    \
+                       IO_HEAD_ARGS(io));
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
@@ -144,19 +181,17 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 
 template <int LPE, int MW>
 hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
-    hipLaunchKernelGGL((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,
-                       obs_mode);
-    return hipGetLastError();
+    LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params,
+                   IO_HEAD_ARGS(io), T, obs_mode);
 }
 
 hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
-        hipLaunchKernelGGL((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),   \
-                           dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
-                           obs_mode);                                                                               \
-        return hipGetLastError();
+        LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),       \
+                       dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,   \
+                       obs_mode);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
@@ -197,6 +232,16 @@ hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s)
 }  // namespace
 
 static int alloc_device_state(mapf_engine *e);
+
+// Host writes to an env's stream or free-cell tables void the placements pre-drawn from them (kSlotInvalid).
+static hipError_t invalidate_slots(mapf_engine *e) {
+    return hipMemset(e->p.next_sg, 0xFF, (size_t)e->p.B * e->p.N * sizeof(uint32_t));
+}
+// After host writes to positions / goals / counters the MAY_FINISH hint of the last step is stale: force it on
+// (conservative: the sampler skips the env for one step, the next step writes the real hint).
+static hipError_t force_may_finish(mapf_engine *e) {
+    return hipMemset2D(e->d_scal + MAPF_CTR_MAY_FINISH, kScalInts * sizeof(int), 1, sizeof(int), (size_t)e->p.B);
+}
 
 extern "C" {
 
@@ -260,6 +305,14 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     const int G = 64 / lpe;
     const int B = c.num_envs, N = c.num_agents, H = c.height, W = c.width;
     e->blocks = (B + G - 1) / G;
+    // finite episodes with sampled placements: the env's stream is consumed by reset() alone, so sampler workgroups
+    // behind the env workgroups of k_step pre-draw the next placement (mapf_kernels.inl: sampler_wave); each of their
+    // waves looks after 64 envs
+#ifndef MAPF_NO_SAMPLER_WG  // (A/B builds: no background sampler, every reset draws inline)
+    if (!cte && !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC))) {
+        e->sampler_blocks = sampler_blocks_for(B, step_threads(lpe) / 64);  // leading (specialised kernels) or trailing
+    }
+#endif
 
     Params &p = e->p;
     memset(&p, 0, sizeof(p));
@@ -333,10 +386,14 @@ static int alloc_device_state(mapf_engine *e) {
     const mapf_config &c = e->cfg;
     Params &p = e->p;
     const int B = p.B, N = p.N, H = p.H;
-    HIP_TRY(e, hipSetDevice(c.device));
+    ON_DEVICE(e);
     const size_t BN = (size_t)B * N;
     HIP_TRY(e, hipMalloc(&e->d_agents, BN * sizeof(AgentRec)));
-    HIP_TRY(e, hipMalloc(&e->d_scal, (size_t)B * kScalInts * sizeof(int)));
+    // env scalars [B][16] followed by the next-episode placement slots [B][N] (slots_of(): the step kernel reaches
+    // them from its preloaded arguments)
+    const size_t scal_bytes = (size_t)B * kScalInts * sizeof(int), slot_bytes = BN * sizeof(uint32_t);
+    HIP_TRY(e, hipMalloc(&e->d_scal, scal_bytes + slot_bytes));
+    HIP_TRY(e, hipMalloc(&e->d_vis_rng, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_ring, BN * p.ring_stride * sizeof(int16_t)));
     HIP_TRY(e, hipMalloc(&e->d_rng, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_rows, (size_t)B * H * sizeof(uint64_t)));
@@ -345,21 +402,25 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMalloc(&e->d_n_free, (size_t)B * sizeof(int)));
     HIP_TRY(e, hipMalloc(&e->d_err, 4 * sizeof(int)));
     HIP_TRY(e, hipMemset(e->d_agents, 0, BN * sizeof(AgentRec)));
-    HIP_TRY(e, hipMemset(e->d_scal, 0, (size_t)B * kScalInts * sizeof(int)));
+    HIP_TRY(e, hipMemset(e->d_scal, 0, scal_bytes));
+    HIP_TRY(e, hipMemset(reinterpret_cast<char *>(e->d_scal) + scal_bytes, 0xFF, slot_bytes));  // kSlotInvalid
+    HIP_TRY(e, hipMemset(e->d_vis_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMemset(e->d_ring, 0, BN * p.ring_stride * sizeof(int16_t)));
     HIP_TRY(e, hipMemset(e->d_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMemset(e->d_err, 0, 4 * sizeof(int)));
     HIP_TRY(e, hipMalloc(&e->d_ep_acc, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
     HIP_TRY(e, hipMemset(e->d_ep_acc, 0, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
     p.ep_acc = e->d_ep_acc;
+    p.next_sg = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(e->d_scal) + scal_bytes);
+    p.vis_rng = e->d_vis_rng;
     p.rng = e->d_rng;
     p.free_cells = e->d_free_cells;
     p.free_rank = e->d_free_rank;
     p.n_free = e->d_n_free;
     p.err = e->d_err;
 #ifdef MAPF_STAMPS
-    HIP_TRY(e, hipMalloc(&e->d_dbg, (size_t)e->blocks * 16 * sizeof(unsigned long long)));
-    HIP_TRY(e, hipMemset(e->d_dbg, 0, (size_t)e->blocks * 16 * sizeof(unsigned long long)));
+    HIP_TRY(e, hipMalloc(&e->d_dbg, (size_t)(e->blocks + e->sampler_blocks) * 16 * sizeof(unsigned long long)));
+    HIP_TRY(e, hipMemset(e->d_dbg, 0, (size_t)(e->blocks + e->sampler_blocks) * 16 * sizeof(unsigned long long)));
 #endif
     p.dbg = e->d_dbg;
     HIP_TRY(e, hipMalloc(&e->d_params, sizeof(Params)));
@@ -370,9 +431,10 @@ static int alloc_device_state(mapf_engine *e) {
 int mapf_destroy(mapf_handle e) {
     if (!e) return MAPF_OK;
     // best effort: a failing free at teardown is reported through the return code, the handle goes away regardless
-    hipError_t first = hipSetDevice(e->cfg.device);
+    DeviceScope scope(e->cfg.device);  // the caller's current device is restored when this returns (e.g. from __del__)
+    hipError_t first = scope.status;
     void *const bufs[] = {e->d_agents, e->d_scal, e->d_ring, e->d_rng, e->d_rows, e->d_free_cells, e->d_free_rank,
-                          e->d_n_free, e->d_err, e->d_ep_acc, e->d_params, e->d_dbg};
+                          e->d_n_free, e->d_err, e->d_ep_acc, e->d_vis_rng, e->d_params, e->d_dbg};
     for (void *b : bufs) {
         const hipError_t rc = hipFree(b);
         if (first == hipSuccess) first = rc;
@@ -413,19 +475,21 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
             return fail(e, MAPF_ERR_FEW_FREE, buf);
         }
     }
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipMemcpy(e->d_rows, rows.data(), rows.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_cells, cells.data(), cells.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_rank, rank.data(), rank.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_n_free, nfree.data(), nfree.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(e, invalidate_slots(e));
     e->grids_set = true;
     return MAPF_OK;
 }
 
 int mapf_set_rng_state(mapf_handle e, const uint64_t *rng_words) {
     if (!e || !rng_words) return fail(e, MAPF_ERR_CONFIG, "null argument");
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipMemcpy(e->d_rng, rng_words, (size_t)e->p.B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, invalidate_slots(e));
     return MAPF_OK;
 }
 
@@ -433,7 +497,7 @@ int mapf_get_state(mapf_handle e, mapf_state *out) {
     if (!e || !out) return fail(e, MAPF_ERR_CONFIG, "null argument");
     const int B = e->p.B, N = e->p.N;
     const size_t BN = (size_t)B * N;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     std::vector<AgentRec> recs(BN);
     HIP_TRY(e, hipMemcpy(recs.data(), e->d_agents, BN * sizeof(AgentRec), hipMemcpyDeviceToHost));
@@ -452,10 +516,24 @@ int mapf_get_state(mapf_handle e, mapf_state *out) {
             out->lock_history[3 * i + 2] = r.progress;
         }
     }
-    if (out->counters)
+    if (out->counters) {
         HIP_TRY(e, hipMemcpy(out->counters, e->d_scal, (size_t)B * kScalInts * sizeof(int), hipMemcpyDeviceToHost));
-    if (out->rng_words)
+        for (int b = 0; b < B; b++) out->counters[(size_t)b * kScalInts + MAPF_CTR_MAY_FINISH] = 0;  // engine-internal
+    }
+    if (out->rng_words) {
+        // the env's visible stream state: while a pre-drawn placement is pending, d_rng already holds the state after
+        // that draw and the visible one is kept in d_vis_rng (mapf_kernels.inl: kSlotInvalid)
         HIP_TRY(e, hipMemcpy(out->rng_words, e->d_rng, (size_t)B * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        std::vector<uint64_t> vis((size_t)B * 6);
+        std::vector<uint32_t> slots(BN);
+        HIP_TRY(e, hipMemcpy(vis.data(), e->d_vis_rng, vis.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(e, hipMemcpy(slots.data(), e->p.next_sg, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; b++) {
+            bool pending = true;  // (a slot is written and voided as a whole; a partly valid one never outlives a launch)
+            for (int n = 0; n < N; n++) pending = pending && slots[(size_t)b * N + n] != kSlotInvalid;
+            if (pending) memcpy(out->rng_words + (size_t)b * 6, vis.data() + (size_t)b * 6, 6 * sizeof(uint64_t));
+        }
+    }
     if (out->distance_ring) {  // ABI layout [B][lw][N], slot = history row index mod lw
         const int lw = e->p.lw, rs = e->p.ring_stride;
         memset(out->distance_ring, 0, BN * lw * sizeof(int16_t));
@@ -488,7 +566,7 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
     if (!e || !in) return fail(e, MAPF_ERR_CONFIG, "null argument");
     const int B = e->p.B, N = e->p.N, H = e->p.H, W = e->p.W;
     const size_t BN = (size_t)B * N;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     const bool ring_in_rec = e->p.lw <= 16;
     const bool touch_recs = in->positions || in->goals || in->starts || in->reached || in->completed_once ||
@@ -541,8 +619,11 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
     }
     if (in->counters)
         HIP_TRY(e, hipMemcpy(e->d_scal, in->counters, (size_t)B * kScalInts * sizeof(int), hipMemcpyHostToDevice));
-    if (in->rng_words)
+    if (in->rng_words) {
         HIP_TRY(e, hipMemcpy(e->d_rng, in->rng_words, (size_t)B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(e, invalidate_slots(e));
+    }
+    HIP_TRY(e, force_may_finish(e));
     if (in->distance_ring && !ring_in_rec) {
         const int lw = e->p.lw, rs = e->p.ring_stride;
         std::vector<int16_t> ring(BN * rs, 0);
@@ -590,8 +671,8 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     io.lds_scratch_off = e->p.lds_scratch_off;
     io.env_mask = env_mask;
     io.obs = obs;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, dispatch(KIND_RESET, e, io, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, dispatch(KIND_RESET, e, io, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -628,8 +709,8 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.info_agent = info_agent;
     io.final_obs = final_obs;
     io.auto_reset = auto_reset;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -666,8 +747,8 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     io.info_all = info_all;
     io.info_agent = info_agent;
     io.auto_reset = 1;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, dispatch_many(e, io, T, obs_mode, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, dispatch_many(e, io, T, obs_mode, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -693,9 +774,8 @@ static CteIo make_cte_io(const mapf_engine *e) {
 static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s) {
 #define MAPF_CASE(L)                                                                                                 \
     case L:                                                                                                          \
-        if (step) hipLaunchKernelGGL((k_cte_step<L>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io);  \
-        else hipLaunchKernelGGL((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);      \
-        return hipGetLastError();
+        if (step) LAUNCH_CHECKED((k_cte_step<L>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io);      \
+        LAUNCH_CHECKED((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     switch (e->lpe) {
         MAPF_CASE(4)
         MAPF_CASE(8)
@@ -720,8 +800,8 @@ int mapf_cte_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *str
     CteIo io = make_cte_io(e);
     io.env_mask = env_mask;
     io.obs = obs;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, launch_cte(e, io, false, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, launch_cte(e, io, false, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -739,8 +819,8 @@ int mapf_cte_step(mapf_handle e, const int8_t *actions, float *obs, double *rewa
     io.info = info;
     io.final_obs = final_obs;
     io.auto_reset = auto_reset;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -768,8 +848,8 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.lds_stage_off = e->p.lds_stage_off;
     io.lds_scratch_off = e->p.lds_scratch_off;
     io.obs = obs;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
+    ON_DEVICE(e);
+    LAUNCH_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
     return MAPF_OK;
 }
 
@@ -777,7 +857,7 @@ int mapf_get_episode_stats(mapf_handle e, int64_t *out, int32_t reset) {
     if (!e || !out) return fail(e, MAPF_ERR_CONFIG, "null argument");
     const size_t n = (size_t)e->p.B * MAPF_NUM_EPISODE_ACC;
     std::vector<int> acc(n);
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(acc.data(), e->d_ep_acc, n * sizeof(int), hipMemcpyDeviceToHost));
     for (int k = 0; k < MAPF_NUM_EPISODE_ACC; k++) out[k] = 0;
@@ -789,7 +869,7 @@ int mapf_get_episode_stats(mapf_handle e, int64_t *out, int32_t reset) {
 int mapf_poll_error(mapf_handle e, void *stream, int32_t *env, int32_t *agent, int32_t *value) {
     if (!e) return MAPF_ERR_CONFIG;
     int rec[4] = {0, 0, 0, 0};
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(e, hipMemcpy(rec, e->d_err, sizeof rec, hipMemcpyDeviceToHost));
     if (rec[0] != 0) {
@@ -802,6 +882,8 @@ int mapf_poll_error(mapf_handle e, void *stream, int32_t *env, int32_t *agent, i
             snprintf(buf, sizeof buf, "Invalid action %d for agent_%d (env %d)", rec[3], rec[2], rec[1]);
         else if (rec[0] == MAPF_ERR_NO_RESPAWN)
             snprintf(buf, sizeof buf, "No valid cell available for lifelong goal reassignment. (env %d, agent_%d)", rec[1], rec[2]);
+        else if (rec[0] == MAPF_ERR_RNG_GUARD)
+            snprintf(buf, sizeof buf, "bounded draw rejected 4096 times in a row: RNG state of env %d is corrupt", rec[1]);
         else
             snprintf(buf, sizeof buf, "device error %d in env %d", rec[0], rec[1]);
         e->err = buf;
@@ -812,9 +894,9 @@ int mapf_poll_error(mapf_handle e, void *stream, int32_t *env, int32_t *agent, i
 int mapf_debug_stamps(mapf_handle e, uint64_t *out, int32_t max_words) {
     if (!e || !out) return MAPF_ERR_CONFIG;
 #ifdef MAPF_STAMPS
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
-    size_t n = (size_t)e->blocks * 16;
+    size_t n = (size_t)(e->blocks + e->sampler_blocks) * 16;  // env workgroups first, then the sampler workgroups
     if ((size_t)max_words < n) n = (size_t)max_words;
     HIP_TRY(e, hipMemcpy(out, e->d_dbg, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)n;

@@ -77,6 +77,8 @@ extern "C" {
 #define MAPF_ERR_CONFIG (-4)      /* config outside this build's limits / inconsistent arguments */
 #define MAPF_ERR_HIP (-5)         /* a HIP runtime call failed */
 #define MAPF_ERR_STATE (-6)       /* call sequence error (e.g. step before grids were set) */
+#define MAPF_ERR_RNG_GUARD (-7)   /* device: a bounded draw was rejected 4096 times in a row (cannot happen with a sound
+                                   * stream state, p < 1e-24000): the env's RNG state is corrupt; latched like the others */
 
 /* info_all[...] column order: the reference's info["__all__"] keys MA-env:639-655 */
 #define MAPF_INFO_ALL 14
@@ -107,6 +109,9 @@ extern "C" {
 #define MAPF_CTR_LIVELOCK_STEPS 7
 #define MAPF_CTR_LOCK_STATE_PREV 8      /* bit0 _deadlock_state_prev, bit1 _livelock_state_prev MA-env:68-69 */
 #define MAPF_CTR_EPISODES_DONE 9        /* episodes finished by this env since create (auto-reset bookkeeping) */
+#define MAPF_CTR_MAY_FINISH 10          /* engine-internal hint, nonzero = the episode may end in the next step (step limit
+                                         * reached, or every agent within one cell of its goal): the background sampler
+                                         * leaves such envs alone.  Written by every step; mapf_set_state forces it on. */
 
 /* per-env lifetime sums over finished episodes, mapf_get_episode_stats() adds them up over the envs:
  * the quantities the reference's RLlib callbacks log at episode end (src/trainers/callbacks.py:135-345) */

@@ -456,3 +456,63 @@ def test_randomized_configuration_fuzz_engine_vs_oracle():
             compare_steppers(EngineStepper(grids, cfg, seeds=seeds, **extra), OracleStepper(grids, cfg, seeds=seeds), acts)
         except AssertionError as exc:
             raise AssertionError(f"fuzz case {case}: cfg={cfg} B={B} HxW={H}x{W} density={density} extra={extra}: {exc}") from exc
+
+
+# ---- episode boundaries: pre-drawn placements, fast / slow reset paths ---------------------------------------
+@pytest.mark.parametrize("want_final", [False, True])
+@pytest.mark.parametrize("shape", [
+    (256, 32, 32, 8, 0.40, {}),                                                  # c3 shape: full waves, specialised kernel
+    (256, 32, 32, 8, 0.40, {"force_generic_kernel": True}),
+    (100, 16, 16, 4, 0.20, {"steps_per_episode": 37}),                           # c2 shape, ragged last wave
+    (50, 9, 9, 3, 0.15, {"steps_per_episode": 23, "include_goal_distance": True}),  # N < lanes per env
+    (40, 10, 10, 6, 0.10, {"steps_per_episode": 3}),                             # episodes shorter than the sampler's lead
+    (40, 10, 10, 6, 0.10, {"steps_per_episode": 1}),
+    (30, 12, 12, 20, 0.20, {"steps_per_episode": 19}),                           # wide groups: LDS cell map, slow reset + slot
+    (64, 8, 8, 5, 0.10, {"steps_per_episode": 11, "force_sequential_reset": True}),  # sampler never succeeds
+    (48, 8, 8, 5, 0.10, {"steps_per_episode": 11, "lanes_per_env": 16}),
+])
+def test_staggered_episode_boundaries_match_the_oracle(shape, want_final):
+    """Envs finish in different steps (staggered phases + short episodes), so every launch mixes envs that are
+    re-placed from a pre-drawn slot, envs that draw inline and envs that do not reset; with and without the
+    terminal observation (final_obs) being asked for.  RNG words are compared at the end."""
+    B, H, W, N, density, extra = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "steps_per_episode": 29,
+           "include_action_mask_in_obs": True}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, density, N, base_seed=310_000)
+    seeds = list(range(500, 500 + B))
+    acts = np.random.default_rng(77).integers(0, 5, size=(150, B, N)).astype(np.int8)
+    spe = cfg["steps_per_episode"]
+    stats = compare_steppers(EngineStepper(grids, cfg, seeds=seeds, want_final_obs=want_final),
+                             OracleStepper(grids, cfg, seeds=seeds), acts, check_state_every=7,
+                             step_counts=np.arange(B) % spe)
+    assert stats["episodes"] >= B * (150 // spe - 1)
+
+
+def test_goal_seeking_policy_ends_episodes_by_success_at_any_step():
+    """Success terminations (every agent on its goal) arrive at arbitrary steps, including the first steps of an
+    episode when the background sampler has not yet provided a placement: greedy actions on open grids."""
+    B, H, W, N = 96, 7, 7, 2
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 1, "steps_per_episode": 40}
+    grids = synth_grids(B, H, W, 0.0, N, base_seed=77_000)
+    seeds = list(range(B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds, want_final_obs=False), OracleStepper(grids, cfg, seeds=seeds)
+    _ = eng.reset(), orc.reset()
+    rng = np.random.default_rng(5)
+    successes = 0
+    for t in range(220):
+        pos, goal = orc.positions().astype(int), orc.goals().astype(int)
+        d = goal - pos
+        # step along the larger-magnitude axis towards the goal (UP 1, RIGHT 2, DOWN 3, LEFT 4), a little noise
+        vert = np.where(d[..., 0] < 0, 1, 3)
+        horz = np.where(d[..., 1] > 0, 2, 4)
+        a = np.where(np.abs(d[..., 0]) >= np.abs(d[..., 1]), vert, horz)
+        a = np.where((d == 0).all(-1), 0, a)
+        a = np.where(rng.random(a.shape) < 0.1, rng.integers(0, 5, a.shape), a).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            assert np.array_equal(ra[k], rb[k]), (k, t)
+        successes += int((rb["terminated"].astype(bool) & ~rb["truncated"].astype(bool)).sum())
+        assert np.array_equal(eng.positions(), orc.positions()) and np.array_equal(eng.goals(), orc.goals()), t
+    assert successes > 5 * B
+    assert np.array_equal(eng.rng_words(), orc.rng_words())

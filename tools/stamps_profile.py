@@ -8,9 +8,10 @@ import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "gpurun_out", "libmapfstep_stamps.so")
+so = os.environ.get("MAPF_STAMPS_LIB") or os.path.join(ROOT, "gpurun_out", "libmapfstep_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
+if not os.environ.get("MAPF_STAMPS_LIB"):  # else: a stamps build made beforehand (hipcc cross-compiles without a GPU)
+  subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
                 "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DMAPF_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so,
                 os.path.join(ROOT, "dl_reference_models_amd", "csrc", "mapf_step.hip")], check=True)
 os.environ["MAPF_LIB"] = so
@@ -33,14 +34,16 @@ for t in range(130):
     env.step(acts[t % 64])
 torch.cuda.synchronize()
 blocks = env.launch_info()["blocks"]
-rows = []
+rows, srows = [], []
 for t in range(20):
     env.step(acts[t % 64])
-    buf = np.zeros(blocks * 16, dtype=np.uint64)
+    buf = np.zeros((blocks + 4096) * 16, dtype=np.uint64)
     n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
-    assert n == buf.size, n
-    rows.append(buf.reshape(blocks, 16).astype(np.int64))
+    assert n >= blocks * 16, n
+    rows.append(buf[: blocks * 16].reshape(blocks, 16).astype(np.int64))
+    srows.append(buf[blocks * 16: n].reshape(-1, 16).astype(np.int64))
 full = np.stack(rows)  # [T, blocks, 16]
+samp = np.stack(srows)  # [T, sampler workgroups, 16]
 st = full[:, :, :10]
 d = np.diff(st, axis=2)
 names = ["loads+sync", "move", "goal/lock/term/table", "pair loop+emit", "flush obs", "lock detector", "outputs",
@@ -64,3 +67,21 @@ if env.launch_info()["threads"] >= 128:  # observation wave, relative to the sta
     print("  state wave stamps at median " + " ".join(f"{np.median(cum[:, :, k]):.0f}" for k in range(10)))
 pre = st[:, :, 0] - full[:, :, 15]
 print(f"  wave entry -> first stamp (scalar loads: kernel arguments + Params): median {np.median(pre):.0f}  p95 {np.percentile(pre, 95):.0f}")
+
+# sampler workgroups (appended to the grid).  s_memtime counters of different workgroups are not comparable (see
+# above), so only durations inside a sampler wave are reported, next to the duration of an env workgroup's state wave
+# (entry -> last store drained) which a sampler wave has to stay under to be invisible.
+if samp.shape[1]:
+    act = samp[:, :, 4] == 1
+    env_dur = full[:, :, 9] - full[:, :, 15]
+    print(f"  sampler workgroups: {samp.shape[1]}, active per launch (median) {np.median(act.sum(axis=1)):.0f}")
+    print(f"  env state wave, entry -> done: median {np.median(env_dur):.0f}  p95 {np.percentile(env_dur, 95):.0f}  "
+          f"slowest of a launch (median) {np.median(env_dur.max(axis=1)):.0f}")
+    d01 = samp[:, :, 1] - samp[:, :, 0]
+    print(f"  sampler wave: entry -> need known  median {np.median(d01):.0f}  p95 {np.percentile(d01, 95):.0f}  (idle waves end here)")
+    if act.any():
+        d12 = (samp[:, :, 2] - samp[:, :, 1])[act]
+        d23 = (samp[:, :, 3] - samp[:, :, 2])[act]
+        d03 = (samp[:, :, 3] - samp[:, :, 0])[act]
+        print(f"  ACTIVE sampler wave: draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f})  gather+store {np.median(d23):.0f} "
+              f"(p95 {np.percentile(d23, 95):.0f})  entry -> slot stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
