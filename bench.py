@@ -212,6 +212,8 @@ def worker(args) -> int:
     b_per = len(env_ids)
     cfg = wl.workload_config(name, env_ids)
     cfg["device"] = str(device)
+    if os.environ.get("MAPF_SEPARATE_OUTPUTS"):  # A/B knob of VecReferenceModel (output tensors in separate allocations)
+        cfg["separate_output_tensors"] = True
     env = VecReferenceModel(cfg)
     L_obs = env.obs_len
     spe = int(cfg["steps_per_episode"])

@@ -59,6 +59,7 @@ constexpr int kRowPad = 5;  // = MAPF_MAX_SENSOR_RANGE
 // therefore just invalidating it (no copy at the episode boundary); host setters of the stream invalidate it too, and
 // mapf_get_state reports vis_rng for envs whose slot is pending.
 constexpr uint32_t kSlotInvalid = 0xFFFFFFFFu;
+constexpr int kDbgRow = 32;  // diagnostic build: s_memtime stamps per workgroup (Params::dbg)
 // next_sg lives behind the env scalars in one allocation, so the step kernel reaches it from preloaded arguments
 __device__ __forceinline__ uint32_t *slots_of(int *scal, int B) {
     return reinterpret_cast<uint32_t *>(scal + (size_t)B * MAPF_NUM_COUNTERS);
@@ -159,7 +160,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         unsigned long long _t;                                                          \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + (k)] = _t; \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + (k)] = _t; \
     } while (0)
 // wave entry time, taken before the first scalar load is waited for; written to slot 15 by MAPF_STAMP_ENTRY_STORE
 #define MAPF_STAMP_ENTRY()                                                              \
@@ -168,7 +169,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
 #define MAPF_STAMP_ENTRY_STORE()                                                        \
     do {                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + 15] = _t_entry; \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 15] = _t_entry; \
     } while (0)
 // the same for the observation wave (lane 64 of a two-wave workgroup), slots 10..14
 #define MAPF_STAMP_W1(k)                                                                \
@@ -177,7 +178,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         unsigned long long _t;                                                          \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * 16 + (k)] = _t; \
+        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + (k)] = _t; \
     } while (0)
 // sampler waves (wave 0 of a sampler workgroup): slots 0 entry, 1 need known, 2 draw done, 3 placement stored, 4 = active
 #define MAPF_STAMP_SW(k)                                                                \
@@ -186,7 +187,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         unsigned long long _t;                                                          \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * 16 + (k)] = _t;            \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * kDbgRow + (k)] = _t;            \
     } while (0)
 #else
 #define MAPF_STAMP_SW(k) do { } while (0)
@@ -856,7 +857,9 @@ __device__ __forceinline__ uint32_t resolve_moves_map(const Params &p, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // observation of every agent lane -> LDS staging row (MA-env:707-747 get_obs, :749-773 mask,
 // :306-335 flatten), fused with the other all-pairs work of a step (MODE below): neighbour sets of
-// the lock detector (MA-env:389-398), intent blocking (:608-623), coincidence penalty (:658-666).
+// the lock detector (MA-env:389-398), intent blocking (:608-623).  (The coincidence penalty MA-env:658-666 is
+// identically zero: agents never share a cell -- the move rule keeps it so and mapf_set_state rejects states that
+// violate it -- so nothing is computed for it.)
 // Pair-table entry of agent j:
 //   x = old | new<<16      y = goal | reached<<16 | (delta+256)<<17      z = intended cell (+1,+1) or ~0
 // final_state: everybody at their new cell (reset, or after a lifelong respawn MA-env:565-575);
@@ -943,7 +946,6 @@ struct PairOut {
     uint64_t nbr;   // agents within lock_nearby_manhattan (final positions), self excluded
     int sum_delta;  // sum over {self} U nbr of (distance at window start - distance now)
     bool blocks;    // some not-yet-reached agent intended to enter my cell
-    int coincide;   // other agents sharing my cell (0 by invariant)
 };
 
 // MODE: kObsEmit = observation only (reset / observe kernels, and the observation wave of a step),
@@ -974,7 +976,7 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     }
 
     uint32_t nbr_lo = 0, nbr_hi = 0;
-    int sum_biased = 0, same_cell = 0;
+    int sum_biased = 0;
     bool blocks = false;
     if (USE_MAP) {
         // ---- large N: read my window and my lock neighbourhood from the env's cell map ----
@@ -1030,7 +1032,6 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
                 }
             }
             blocks = (ctr[0] >> 21) & 1u;
-            same_cell = 1;  // coincidences (unreachable by the move rule) are not tracked on this path
         }
     } else
     for (int j0 = 0; j0 < N; j0 += C) {
@@ -1057,7 +1058,6 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
                 else nbr_hi |= isn ? (1u << (j & 31)) : 0u;
                 sum_biased += isn ? (int)((Bj >> 17) & 1023u) : 0;
                 blocks |= e[u].z == mycell1;
-                same_cell += (newj == cur) ? 1 : 0;
             }
         }
     }
@@ -1065,7 +1065,6 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
         po.nbr = (uint64_t)nbr_lo | ((uint64_t)nbr_hi << 32);
         po.sum_delta = my_delta + sum_biased - 256 * (__popc(nbr_lo) + __popc(nbr_hi));
         po.blocks = blocks;
-        po.coincide = same_cell - 1;  // the loop counted me as well
     }
     if (!EMIT || !is_agent) return;
 
@@ -1642,6 +1641,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     // intended_next (MA-env:514-515) in the (+1,+1) encoding; may lie outside the grid
     const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
     uint32_t cur = old;
+    MAPF_STAMP(16);  // (sub-stamp: target cell known)
     constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
     const bool use_map = MAP_OK && io.use_map;
     const int map_w = W + 2 * kRowPad;
@@ -1732,6 +1732,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (obs_wave && !lifelong && !use_map) {  // finite episodes: goals are fixed, the observation only waited for the moves
         otabg[a] = obs_entry(false);
         wg_sync();  // B1
+        MAPF_STAMP(19);  // (sub-stamp: finite mode, observation wave released)
     }
 
     if (!lifelong) {
@@ -1877,7 +1878,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                                    sc[MAPF_CTR_STEP_COUNT] + 1 >= io.steps_per_episode) ? 1 : 0;
 
     // observations (MA-env:528-534 staggered, or :565-575 all-final after a respawn) fused with the
-    // neighbour / blocking / coincidence pass
+    // neighbour / blocking pass
     PairOut po;
     float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
     // this wave builds the observation itself unless the other wave does, or nobody asked for one (fused steps
@@ -1941,7 +1942,6 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     MAPF_STAMP(5);
 
     reward += term_reward;
-    reward -= (float)po.coincide;  // unreachable by invariant; kept like the reference (MA-env:658-666)
     // blocking flags feed NEXT step's observation (MA-env:608-625)
     const bool blocking = is_agent && reached && !moved && po.blocks;
 
@@ -1960,6 +1960,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (io.terminated) io.terminated[env] = (uint8_t)term;
         if (io.truncated) io.truncated[env] = (uint8_t)trunc;
     }
+    MAPF_STAMP(17);  // (sub-stamp: rewards / per-agent info / done flags issued)
     bool records_stored = false;
     if (FAST && rec0 != nullptr && !__any(slow_reset)) {
         st.pos = cur;
@@ -1980,6 +1981,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         records_stored = true;
     }
 
+    MAPF_STAMP(18);  // (sub-stamp: agent records issued)
     // lock detector (MA-env:400-438): deadlock has priority over livelock
     using gm_t = typename GMask<LPE>::type;
     int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
@@ -2048,6 +2050,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                 }
             }
             wave_lds_sync();
+            MAPF_STAMP(20);  // (sub-stamp: info / counters staged in LDS)
             if (io.info_all) {
                 float2 *dst = reinterpret_cast<float2 *>(io.info_all + (size_t)env0 * MAPF_INFO_ALL);
                 for (int k = lane; k < G * 7; k += 64) dst[k] = xi[k];
@@ -2233,7 +2236,7 @@ __device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, int1
     uint64_t need = __ballot((int)in & (int)(slot0 == kSlotInvalid) & (int)(hint == 0));
     MAPF_STAMP_SW(1);
 #ifdef MAPF_STAMPS
-    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * 16 + 4] = need ? 1 : 0;
+    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * kDbgRow + 4] = need ? 1 : 0;
 #endif
     // ONE round per launch: the first G envs in need are served, the others in a later launch (an episode that ends
     // before its turn draws inline, like any env without a slot).  A wave's work is thereby bounded by one draw, which

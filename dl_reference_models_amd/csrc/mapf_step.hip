@@ -62,6 +62,7 @@ struct mapf_engine {
     int sampler_blocks = 0;  // k_step only: workgroups appended to the grid that pre-draw next-episode placements
     int lds_bytes = 0;
     bool grids_set = false;
+    std::vector<uint64_t> h_rows;  // host copy of the obstacle rows (mapf_set_state validates injected positions against it)
     std::string err;
     // device allocations
     AgentRec *d_agents = nullptr;
@@ -419,8 +420,8 @@ static int alloc_device_state(mapf_engine *e) {
     p.n_free = e->d_n_free;
     p.err = e->d_err;
 #ifdef MAPF_STAMPS
-    HIP_TRY(e, hipMalloc(&e->d_dbg, (size_t)(e->blocks + e->sampler_blocks) * 16 * sizeof(unsigned long long)));
-    HIP_TRY(e, hipMemset(e->d_dbg, 0, (size_t)(e->blocks + e->sampler_blocks) * 16 * sizeof(unsigned long long)));
+    HIP_TRY(e, hipMalloc(&e->d_dbg, (size_t)(e->blocks + e->sampler_blocks) * kDbgRow * sizeof(unsigned long long)));
+    HIP_TRY(e, hipMemset(e->d_dbg, 0, (size_t)(e->blocks + e->sampler_blocks) * kDbgRow * sizeof(unsigned long long)));
 #endif
     p.dbg = e->d_dbg;
     HIP_TRY(e, hipMalloc(&e->d_params, sizeof(Params)));
@@ -481,6 +482,7 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
     HIP_TRY(e, hipMemcpy(e->d_free_rank, rank.data(), rank.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_n_free, nfree.data(), nfree.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(e, invalidate_slots(e));
+    e->h_rows = rows;
     e->grids_set = true;
     return MAPF_OK;
 }
@@ -595,6 +597,32 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
                 r.moved = in->lock_history[3 * i];
                 r.failed = in->lock_history[3 * i + 1];
                 r.progress = in->lock_history[3 * i + 2];
+            }
+        }
+        // The move rule keeps agents on distinct free cells and goals distinct (MA-env:502-526, :284-304); everything
+        // downstream (time-indexed occupancy, cell maps, respawn ranks) relies on it, and the reference's own
+        // behaviour with two agents in one cell is an artefact of its owner maps (the collision penalty MA-env:658-666
+        // is dead code there too).  Injected states must therefore satisfy the invariant.
+        if (in->positions || in->goals) {
+            const int pad = e->col_pad;
+            std::vector<uint32_t> seen;
+            for (int b = 0; b < B; b++) {
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 0 ? !in->positions : !in->goals) continue;
+                    seen.clear();
+                    for (int n = 0; n < N; n++) {
+                        const AgentRec &r = recs[(size_t)b * N + n];
+                        const uint32_t cell = pass == 0 ? (r.w0 & 0xFFFFu) : (r.w0 >> 16);
+                        for (uint32_t o : seen)
+                            if (o == cell)
+                                return fail(e, MAPF_ERR_CONFIG, pass == 0 ? "two agents of an env on the same cell"
+                                                                          : "two agents of an env with the same goal cell");
+                        seen.push_back(cell);
+                        if (pass == 0 && e->grids_set &&
+                            ((e->h_rows[(size_t)b * H + (cell >> 8)] >> ((cell & 255u) + pad)) & 1ull))
+                            return fail(e, MAPF_ERR_CONFIG, "agent position on an obstacle cell");
+                    }
+                }
             }
         }
         if (in->distance_ring && ring_in_rec) {
@@ -896,7 +924,7 @@ int mapf_debug_stamps(mapf_handle e, uint64_t *out, int32_t max_words) {
 #ifdef MAPF_STAMPS
     ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
-    size_t n = (size_t)(e->blocks + e->sampler_blocks) * 16;  // env workgroups first, then the sampler workgroups
+    size_t n = (size_t)(e->blocks + e->sampler_blocks) * kDbgRow;  // env workgroups first, then the sampler workgroups
     if ((size_t)max_words < n) n = (size_t)max_words;
     HIP_TRY(e, hipMemcpy(out, e->d_dbg, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)n;

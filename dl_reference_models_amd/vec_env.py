@@ -164,11 +164,23 @@ class VecReferenceModel:
             Lo = self.obs_len
             self._obs = torch.zeros((B, N, Lo), dtype=torch.float32, device=dev)
             self._final_obs = torch.zeros((B, N, Lo), dtype=torch.float32, device=dev)
-            self._rewards = torch.zeros((B, N), dtype=torch.float32, device=dev)
-            self._terminated = torch.zeros((B,), dtype=torch.uint8, device=dev)
-            self._truncated = torch.zeros((B,), dtype=torch.uint8, device=dev)
-            self._info_all = torch.zeros((B, L.INFO_ALL), dtype=torch.float32, device=dev)
-            self._info_agent = torch.zeros((B, N, 2), dtype=torch.uint8, device=dev)
+            # the small per-step outputs live in ONE allocation (256-byte aligned sections): a wave's stores to them
+            # then share address translations instead of touching five separately mapped tensors
+            shapes = (("_rewards", (B, N), torch.float32), ("_info_all", (B, L.INFO_ALL), torch.float32),
+                      ("_info_agent", (B, N, 2), torch.uint8), ("_terminated", (B,), torch.uint8),
+                      ("_truncated", (B,), torch.uint8))
+            if cfg.get("separate_output_tensors", False):  # (A/B knob)
+                for name, shape, dt in shapes:
+                    setattr(self, name, torch.zeros(shape, dtype=dt, device=dev))
+            else:
+                sizes = [int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() for _, shape, dt in shapes]
+                offs, total = [], 0
+                for sz in sizes:
+                    offs.append(total)
+                    total += (sz + 255) & ~255
+                self._out_blob = torch.zeros((total,), dtype=torch.uint8, device=dev)
+                for (name, shape, dt), off, sz in zip(shapes, offs, sizes):
+                    setattr(self, name, self._out_blob[off:off + sz].view(dt).view(shape))
 
         if self.deterministic:
             # fixed start/goal tables (MA-env:124-132)

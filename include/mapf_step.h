@@ -245,7 +245,7 @@ int mapf_get_episode_stats(mapf_handle h, int64_t *out /* host */, int32_t reset
 int mapf_poll_error(mapf_handle h, void *stream, int32_t *env, int32_t *agent, int32_t *value);
 
 /* diagnostic builds only (-DMAPF_STAMPS; the shipped library returns MAPF_ERR_STATE): copies the per-wave
- * s_memtime stamps of the last mapf_step to host uint64 out[blocks][16]; returns the number of words. */
+ * s_memtime stamps of the last mapf_step to host uint64 out[workgroups][32]; returns the number of words. */
 int mapf_debug_stamps(mapf_handle h, uint64_t *out /* host */, int32_t max_words);
 
 /* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes).

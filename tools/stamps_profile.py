@@ -34,14 +34,15 @@ for t in range(130):
     env.step(acts[t % 64])
 torch.cuda.synchronize()
 blocks = env.launch_info()["blocks"]
+ROW = 32  # words per workgroup (kDbgRow)
 rows, srows = [], []
 for t in range(20):
     env.step(acts[t % 64])
-    buf = np.zeros((blocks + 4096) * 16, dtype=np.uint64)
+    buf = np.zeros((blocks + 4096) * ROW, dtype=np.uint64)
     n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
-    assert n >= blocks * 16, n
-    rows.append(buf[: blocks * 16].reshape(blocks, 16).astype(np.int64))
-    srows.append(buf[blocks * 16: n].reshape(-1, 16).astype(np.int64))
+    assert n >= blocks * ROW, n
+    rows.append(buf[: blocks * ROW].reshape(blocks, ROW).astype(np.int64))
+    srows.append(buf[blocks * ROW: n].reshape(-1, ROW).astype(np.int64))
 full = np.stack(rows)  # [T, blocks, 16]
 samp = np.stack(srows)  # [T, sampler workgroups, 16]
 st = full[:, :, :10]
@@ -65,6 +66,14 @@ if env.launch_info()["threads"] >= 128:  # observation wave, relative to the sta
         print(f"  {nme:30s} at median {np.median(w1[:, :, k]):9.0f}  p95 {np.percentile(w1[:, :, k], 95):9.0f}")
     cum = st - st[:, :, 0:1]
     print("  state wave stamps at median " + " ".join(f"{np.median(cum[:, :, k]):.0f}" for k in range(10)))
+# sub-stamps (slots 16..20), relative to the state wave's first stamp
+sub = {16: "target cell known (move phase)", 19: "observation wave released (after B1)", 17: "rewards / flags issued", 18: "agent records issued",
+       20: "info / counters staged"}
+for k, nme in sub.items():
+    v = full[:, :, k] - st[:, :, 0]
+    v = v[full[:, :, k] > 0]
+    if v.size:
+        print(f"  sub-stamp {nme:38s} at median {np.median(v):7.0f}  p95 {np.percentile(v, 95):7.0f}")
 pre = st[:, :, 0] - full[:, :, 15]
 print(f"  wave entry -> first stamp (scalar loads: kernel arguments + Params): median {np.median(pre):.0f}  p95 {np.percentile(pre, 95):.0f}")
 
