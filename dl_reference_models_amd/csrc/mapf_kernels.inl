@@ -59,10 +59,37 @@ constexpr int kRowPad = 5;  // = MAPF_MAX_SENSOR_RANGE
 // therefore just invalidating it (no copy at the episode boundary); host setters of the stream invalidate it too, and
 // mapf_get_state reports vis_rng for envs whose slot is pending.
 constexpr uint32_t kSlotInvalid = 0xFFFFFFFFu;
+// The background draw is split over two launches (sampler_wave): after its first half the env's word 0 reads kSlotStaged
+// (the stream is advanced and vis_rng set as for a pending slot, the bounded draws wait in Params::stage_vals); the
+// second half turns it into a valid slot.  Consumers treat a staged slot as "none" and draw inline from vis_rng.
+constexpr uint32_t kSlotStaged = 0xFFFFFFFEu;
+// The specialised finite kernels slice the draw finer still and run it in the observation wave of the env's own
+// workgroup (draw_slice), seven slices of at most ~1.5 k cycles: kSlotStaged = later half of the raw outputs done
+// (stream advanced), kSlotStaged2 = all of them, kSlotStaged3 = bounded draws, kSlotStaged4 / 5 = Floyd (two
+// halves), kSlotStaged6 = shuffle; the free-cell gather then makes the slot valid.
+constexpr uint32_t kSlotStaged2 = 0xFFFFFFFDu, kSlotStaged3 = 0xFFFFFFFCu, kSlotStaged4 = 0xFFFFFFFBu,
+                   kSlotStaged5 = 0xFFFFFFFAu, kSlotStaged6 = 0xFFFFFFF9u,
+                   kSlotStageFailed = 0xFFFFFFF8u;  // (a bounded draw might be rejected: the env will draw inline)
+__host__ __device__ constexpr int stage_dwords(int N) { return 4 * N + 4; }  // Params::stage_vals per env
+__device__ __forceinline__ bool slot_word_valid(uint32_t w) { return w < 0xFFFFFFF0u; }  // cells are < 0x4000
+__device__ __forceinline__ bool slot_word_staged(uint32_t w) { return !slot_word_valid(w) && w != kSlotInvalid; }
 constexpr int kDbgRow = 32;  // diagnostic build: s_memtime stamps per workgroup (Params::dbg)
 // next_sg lives behind the env scalars in one allocation, so the step kernel reaches it from preloaded arguments
-__device__ __forceinline__ uint32_t *slots_of(int *scal, int B) {
+__host__ __device__ __forceinline__ uint32_t *slots_of(int *scal, int B) {
     return reinterpret_cast<uint32_t *>(scal + (size_t)B * MAPF_NUM_COUNTERS);
+}
+// ... and behind the slots: the env streams [B][6] uint64 (Params::rng) and the free-cell counts [B] (Params::n_free),
+// so that a sampler wave can fetch them in its first round trip without waiting for Params
+__host__ __device__ __forceinline__ uint64_t *streams_of(int *scal, int B, int N) {
+    const size_t slot_bytes = ((size_t)B * N * sizeof(uint32_t) + 15) & ~(size_t)15;
+    return reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(slots_of(scal, B)) + slot_bytes);
+}
+__host__ __device__ __forceinline__ int *free_counts_of(int *scal, int B, int N) {
+    return reinterpret_cast<int *>(streams_of(scal, B, N) + (size_t)B * 6);
+}
+__host__ __device__ inline size_t scal_block_bytes(int B, int N) {
+    return (size_t)B * MAPF_NUM_COUNTERS * sizeof(int) + (((size_t)B * N * sizeof(uint32_t) + 15) & ~(size_t)15) +
+           (size_t)B * 6 * sizeof(uint64_t) + (size_t)B * sizeof(int);
 }
 
 // Engine constants, resident in device memory and read through a __restrict__ pointer (scalar loads
@@ -85,6 +112,7 @@ struct Params {
     int *err;                    // [4] code, env, agent, value
     int *ep_acc;                 // [B][MAPF_NUM_EPISODE_ACC] lifetime per-env sums over finished episodes
     uint32_t *next_sg;           // [B][N] pre-sampled placement of the NEXT episode: start | goal << 16, kSlotInvalid = none
+    uint32_t *stage_vals;        // [B][stage_dwords(N)] intermediate data of a staged background draw (kSlotStaged*)
     uint64_t *vis_rng;           // [B][6] while a slot is pending: the env's stream state BEFORE the pre-draw, i.e. what
                                  // NumPy's bit_generator.state shows at that point (Params::rng already holds the state after)
     unsigned long long *dbg;     // diagnostic build only (-DMAPF_STAMPS): [blocks][16] s_memtime stamps
@@ -122,6 +150,11 @@ struct IoTail {
     float *final_obs;
     const uint8_t *env_mask;
     int auto_reset;
+    // sliced background draw (draw_slice): as kernel arguments these are global-address-space pointers; read through
+    // Params they are generic and their loads (flat_*) would sit in the LDS wait counter of the observation wave
+    uint32_t *stage_vals;
+    const uint16_t *free_cells;
+    uint64_t *vis_rng;
 };
 struct Io : IoHead, IoTail {};
 #define MAPF_IO_HEAD_PARAMS                                                                                          \
@@ -217,6 +250,7 @@ __host__ __device__ constexpr int sampler_blocks_for(int B, int waves_per_wg) {
 struct KRuntime {
     static constexpr bool kFixed = false;
     static constexpr bool kSamplerFront = false;
+    static constexpr bool kSlicedDraw = false;
     __device__ static __forceinline__ int N(const Params &p) { return p.N; }
     __device__ static __forceinline__ int sr(const Params &p) { return p.sr; }
     __device__ static __forceinline__ int V(const Params &p) { return p.V; }
@@ -233,7 +267,10 @@ struct KRuntime {
 template <int N_, int SR_, uint32_t FLAGS_, int DW_, int LW_, int NEARBY_, int MINN_>
 struct KFixed {
     static constexpr bool kFixed = true;
-    static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0;
+    // finite episodes with sampled placements and at most 16 cells to draw: the background draw runs in slices in
+    // the observation wave of the env's own workgroup (draw_slice), no sampler workgroups
+    static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && N_ <= 8;
+    static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && !kSlicedDraw;
     __device__ static __forceinline__ int N(const Params &) { return N_; }
     __device__ static __forceinline__ int sr(const Params &) { return SR_; }
     __device__ static __forceinline__ int V(const Params &) { return 2 * SR_ + 1; }
@@ -1230,23 +1267,42 @@ __device__ __forceinline__ uint4 static_entry(uint32_t pos, uint32_t goal) {
 //   * the shuffle swaps run on the LDS copy.
 // Scratch of the group: raw32[4N + 2] | vals[4N] (uint16) | out[2N] (int16).  Returns false for a group that has to
 // take the sequential path; on true, out (at scratch + kSampleOutOff(N)) holds idx and the stream state after the
-// draws is stored to Params::rng[env]; with vis_dst (a pre-drawn placement) the state before them goes to vis_dst[env].
+// draws is stored to Params::rng[env].  The two halves below are separate functions because the background sampler
+// runs them in different launches (sampler_wave).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int sample_out_off_i16(int N) { return 2 * (4 * N + 2) + 4 * N; }
 
-struct PcgPre {  // stream state and free-cell count fetched by the caller (background sampler), or nothing
+struct PcgPre {  // fetched ahead by the caller (background sampler): stream state, free-cell count and this lane's
+                 // jump-ahead constants A[a+1], S[a+1]; or nothing
     bool have;
     Pcg g;
     int pop;
+    uint4 ja, js;  // {hi.lo32, hi.hi32, lo.lo32, lo.hi32} as stored in kPcgJumpA / kPcgJumpS
 };
+// First half: the raw outputs (jump-ahead) and all bounded draws -> vals[4N - 1] in the group's scratch.  Returns
+// whether the lane-parallel draw stands (else: sequential restatement); then the stream after the draws is in
+// Params::rng[env] and, with vis_dst, the stream before them in vis_dst[env].  rng_src: where the stream is read from.
 template <int LPE>
-__device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, int16_t *scr, int lane, int a, int env,
-                                                             bool env_ok, bool do_reset, int N, uint64_t *vis_dst,
-                                                             const PcgPre &pre = PcgPre{false, {}, 0}) {
+__device__ __forceinline__ bool draw_stage_a(const Params &p, int16_t *scr, int lane, int a, int env, bool env_ok,
+                                             bool do_reset, int N, uint64_t *vis_dst, const PcgPre &pre,
+                                             const uint64_t *rng_src, int &pop_out, const int sw_row = -1,
+                                             const int mode = 0, uint64_t *rng_dst = nullptr, const int qpass = -1,
+                                             uint32_t *raw_dst = nullptr) {
+    // qpass (mode 1 only): -1 every output; 0 the lane's first output only (q = a + 1); 1 its second only
+    // (q = a + 1 + LPE, straight from the jump tables; this pass holds the last output and stores the streams).
+    // raw_dst: the outputs also go to this (global) array.
+    if (!rng_dst) rng_dst = p.rng;  // (the sliced draw passes the same array as a global-address-space pointer)
+    // mode 0: both parts; 1: outputs only (raw[] left in the scratch, the streams are stored right away: a later
+    // rejection is then resolved from vis_dst); 2: bounded draws only (raw[] already in the scratch, pop in pre.pop)
+    (void)sw_row;
+#ifdef MAPF_STAMPS
+#define MAPF_STAMP_A(k) do { if (sw_row >= 0) { MAPF_STAMP_SW(k); } } while (0)
+#else
+#define MAPF_STAMP_A(k) do { } while (0)
+#endif
     const int size = 2 * N, D = 2 * size - 1;  // bounded draws of one reset
     uint32_t *raw = reinterpret_cast<uint32_t *>(scr);
     uint16_t *vals = reinterpret_cast<uint16_t *>(raw + 4 * N + 2);
-    int16_t *out = scr + sample_out_off_i16(N);
     Pcg g;
     g.shi = g.slo = g.ihi = g.ilo = 0;
     g.has32 = g.uinteger = 0;
@@ -1257,9 +1313,10 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
             pop = pre.pop;
         }
     } else if (do_reset) {
-        pcg_load(g, p.rng + (size_t)env * 6);
+        pcg_load(g, rng_src + (size_t)env * 6);
         pop = p.n_free[env];
     }
+    pop_out = pop;
     bool ok = do_reset && pop > size && !(p.flags & MAPF_FLAG_SEQUENTIAL_RESET);
     const int has = (int)g.has32;
     const int nout = (D - has + 1) >> 1;  // 64-bit outputs consumed; the stream of 32-bit halves is
@@ -1269,76 +1326,144 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
     const U128 stride_c = mul128(U128{kPcgJumpS[LPE][0], kPcgJumpS[LPE][1]}, inc);
     U128 st = s0, fin = s0;
     uint32_t fin_hi32 = 0;
-    for (int q = a + 1; q <= nout; q += LPE) {
-        if (q == a + 1)
-            st = add128(mul128(U128{kPcgJumpA[q][0], kPcgJumpA[q][1]}, s0), mul128(U128{kPcgJumpS[q][0], kPcgJumpS[q][1]}, inc));
-        else
+    for (int q = a + 1 + (qpass == 1 ? LPE : 0); mode != 2 && q <= nout; q += LPE) {
+        if (q == a + 1 || qpass == 1) {
+            U128 ja = {kPcgJumpA[q][0], kPcgJumpA[q][1]}, js = {kPcgJumpS[q][0], kPcgJumpS[q][1]};
+            if (pre.have && qpass != 1) {
+                ja = U128{(uint64_t)pre.ja.x | ((uint64_t)pre.ja.y << 32), (uint64_t)pre.ja.z | ((uint64_t)pre.ja.w << 32)};
+                js = U128{(uint64_t)pre.js.x | ((uint64_t)pre.js.y << 32), (uint64_t)pre.js.z | ((uint64_t)pre.js.w << 32)};
+            }
+            st = add128(mul128(ja, s0), mul128(js, inc));
+        } else {
             st = add128(mul128(stride_a, st), stride_c);
+        }
         const uint64_t o = pcg_output(st);
         raw[has + 2 * (q - 1)] = (uint32_t)o;
         raw[has + 2 * (q - 1) + 1] = (uint32_t)(o >> 32);
+        if (raw_dst && do_reset) {
+            raw_dst[has + 2 * (q - 1)] = (uint32_t)o;
+            raw_dst[has + 2 * (q - 1) + 1] = (uint32_t)(o >> 32);
+        }
         if (q == nout) {
             fin = st;
             fin_hi32 = (uint32_t)(o >> 32);
         }
+        if (qpass == 0) break;
     }
-    if (has && a == 0) raw[0] = g.uinteger;
+    if (mode != 2 && has && a == 0) {
+        raw[0] = g.uinteger;
+        if (raw_dst && do_reset && qpass != 1) raw_dst[0] = g.uinteger;
+    }
+    const bool store_streams_now = mode == 1 && ok && qpass != 0;
+    if (store_streams_now && env_ok && ((nout - 1) % LPE) == a) {
+        Pcg f;
+        f.shi = fin.hi; f.slo = fin.lo; f.ihi = g.ihi; f.ilo = g.ilo;
+        f.has32 = (uint32_t)(has + 2 * nout - D);
+        f.uinteger = fin_hi32;
+        if (vis_dst) pcg_store(g, vis_dst + (size_t)env * 6);
+        pcg_store(f, rng_dst + (size_t)env * 6);
+    }
     wave_lds_sync();
-    // all bounded draws at once: vals[k] = (raw[k] * (bound_k + 1)) >> 32 unless Lemire would reject
+    if (mode == 1) return ok;
+    MAPF_STAMP_A(6);
+    // all bounded draws at once: vals[k] = (raw[k] * (bound_k + 1)) >> 32 unless Lemire might reject.  Lemire rejects
+    // when the low half `left` is below 2^32 mod excl, which is itself below excl: `left < excl` (probability
+    // excl / 2^32 < 1e-6) is taken as "might" and sends the group to the sequential restatement, which decides exactly;
+    // no modulo here (the compiler evaluated it unconditionally: 3 k cycles of a sampler wave's 7 k).
     bool rej = false;
     for (int k = a; k < D; k += LPE) {
         const uint32_t rng = (uint32_t)(k < size ? pop - size + k : size - 1 - (k - size));
         const uint32_t excl = rng + 1u;
         const uint64_t m = (uint64_t)raw[k] * excl;
-        const uint32_t left = (uint32_t)m;
-        if (left < excl) rej |= left < (0xFFFFFFFFu - rng) % excl;
+        rej |= (uint32_t)m < excl;
         vals[k] = (uint16_t)(m >> 32);
     }
     ok = ok && gballot<LPE>(rej, lane) == 0;
+    MAPF_STAMP_A(7);
+    // the stream after D draws: state_nout; a half is left in the buffer when the number of halves used is odd
+    if (mode == 0 && ok && env_ok && ((nout - 1) % LPE) == a) {
+        Pcg f;
+        f.shi = fin.hi; f.slo = fin.lo; f.ihi = g.ihi; f.ilo = g.ilo;
+        f.has32 = (uint32_t)(has + 2 * nout - D);
+        f.uinteger = fin_hi32;  // NumPy keeps the last high half in the buffer field even once it has been handed out
+        if (vis_dst) pcg_store(g, vis_dst + (size_t)env * 6);
+        pcg_store(f, p.rng + (size_t)env * 6);
+    }
     wave_lds_sync();
-    // Floyd: lane t holds the chosen values number t and t + LPE.  Up to 16 entries (N <= 8) the drawn values live
-    // in registers (static indices: the loops are unrolled to 16 and predicated), so the dependent chain of an
-    // iteration is compare -> ballot -> select with no LDS access in it.
+    MAPF_STAMP_A(8);
+    return ok;
+}
+
+// Floyd's sampling for at most 16 values (N <= 8): lane t ends up with the chosen values number t (c0) and t + LPE (c1).
+// The drawn values live in registers (static indices: the loops are unrolled to 16 and predicated), so the dependent
+// chain of an iteration is compare -> ballot -> select with no LDS access in it.
+// half: -1 = all iterations (c0, c1 start empty); 0 = iterations k < LPE (fills c0); 1 = iterations k >= LPE (c0 is
+// given, fills c1).
+template <int LPE>
+__device__ __forceinline__ void draw_floyd16(int16_t *scr, int lane, int a, int N, int pop, int &c0, int &c1,
+                                             const int half = -1) {
+    const int size = 2 * N;
+    const uint32_t *v32 = reinterpret_cast<const uint32_t *>(scr) + 4 * N + 2;  // vals[] as packed pairs
+    uint32_t vw[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) vw[q] = v32[q];
+    if (half != 1) c0 = -1;
+    c1 = -1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < size && (half < 0 || (half == 0) == (k < LPE))) {
+            const int val = (int)((vw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), j = pop - size + k;
+            const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+            const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
+            if (a == (k & (LPE - 1))) {
+                if (k < LPE) c0 = chosen;
+                else c1 = chosen;
+            }
+        }
+    }
+}
+// _shuffle_int tail shuffle with the precomputed indices vals[2N ..): the permutation fits one 64-bit register as
+// nibbles; every lane applies the swaps to it and then places its chosen values in out[] (group scratch).
+template <int LPE>
+__device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, int N, int c0, int c1) {
+    (void)lane;
+    const int size = 2 * N;
+    const uint16_t *vals = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint32_t *>(scr) + 4 * N + 2);
+    const uint32_t *j32 = reinterpret_cast<const uint32_t *>(vals + size);  // size is even: 4-byte aligned
+    int16_t *out = scr + sample_out_off_i16(N);
+    uint32_t jw[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) jw[q] = j32[q];
+    uint64_t perm = 0xFEDCBA9876543210ull;  // nibble x = which chosen value ends up at position x
+#pragma unroll
+    for (int t = 0; t < 15; t++) {
+        if (t < size - 1) {
+            const int i = size - 1 - t;
+            const int j = (int)((jw[t >> 1] >> (16 * (t & 1))) & 0xFFFFu);
+            const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 15ull;
+            perm ^= (d << (4 * i)) | (d << (4 * j));
+        }
+    }
+    // chosen value t sits at the position x with nibble x == t: scatter through LDS, then every position is read
+    uint8_t *inv = reinterpret_cast<uint8_t *>(out + size);  // [16] position of chosen value t
+    for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
+    wave_lds_sync();
+    if (a < size) out[inv[a]] = (int16_t)c0;
+    if (a + LPE < size) out[inv[a + LPE]] = (int16_t)c1;
+}
+
+// Second half: Floyd's sampling and the tail shuffle on vals[] (group scratch) -> out[2N] (group scratch).
+template <int LPE>
+__device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool ok, int N, int pop) {
+    const int size = 2 * N;
+    uint32_t *raw = reinterpret_cast<uint32_t *>(scr);
+    uint16_t *vals = reinterpret_cast<uint16_t *>(raw + 4 * N + 2);
+    int16_t *out = scr + sample_out_off_i16(N);
+    // Floyd: lane t holds the chosen values number t and t + LPE
     int c0 = -1, c1 = -1;
     if (size <= 16) {
-        uint32_t vw[8], jw[8];  // vals[0 .. 16) and vals[size .. size + 16) as packed pairs
-        const uint32_t *v32 = reinterpret_cast<const uint32_t *>(vals);
-        const uint32_t *j32 = reinterpret_cast<const uint32_t *>(vals + size);  // size is even: 4-byte aligned
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            vw[q] = v32[q];
-            jw[q] = j32[q];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (k < size) {
-                const int val = (int)((vw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu), j = pop - size + k;
-                const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
-                const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
-                if (a == (k & (LPE - 1))) {
-                    if (k < LPE) c0 = chosen;
-                    else c1 = chosen;
-                }
-            }
-        }
-        // _shuffle_int tail shuffle with the precomputed indices: the permutation fits one 64-bit register as
-        // nibbles; every lane applies the swaps to it and then places its chosen values
-        uint64_t perm = 0xFEDCBA9876543210ull;  // nibble x = which chosen value ends up at position x
-#pragma unroll
-        for (int t = 0; t < 15; t++) {
-            if (t < size - 1) {
-                const int i = size - 1 - t;
-                const int j = (int)((jw[t >> 1] >> (16 * (t & 1))) & 0xFFFFu);
-                const uint64_t d = ((perm >> (4 * i)) ^ (perm >> (4 * j))) & 15ull;
-                perm ^= (d << (4 * i)) | (d << (4 * j));
-            }
-        }
-        // chosen value t sits at the position x with nibble x == t: scatter through LDS, then every position is read
-        uint8_t *inv = reinterpret_cast<uint8_t *>(out + size);  // [16] position of chosen value t
-        for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
-        wave_lds_sync();
-        if (a < size) out[inv[a]] = (int16_t)c0;
-        if (a + LPE < size) out[inv[a + LPE]] = (int16_t)c1;
+        draw_floyd16<LPE>(scr, lane, a, N, pop, c0, c1);
+        draw_shuffle16<LPE>(scr, lane, a, N, c0, c1);
     } else {
         for (int k = 0; k < size; k++) {
             const int val = (int)vals[k], j = pop - size + k;
@@ -1361,16 +1486,16 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
             }
         }
     }
-    // the stream after D draws: state_nout; a half is left in the buffer when the number of halves used is odd
-    if (ok && env_ok && ((nout - 1) % LPE) == a) {
-        Pcg f;
-        f.shi = fin.hi; f.slo = fin.lo; f.ihi = g.ihi; f.ilo = g.ilo;
-        f.has32 = (uint32_t)(has + 2 * nout - D);
-        f.uinteger = fin_hi32;  // NumPy keeps the last high half in the buffer field even once it has been handed out
-        if (vis_dst) pcg_store(g, vis_dst + (size_t)env * 6);
-        pcg_store(f, p.rng + (size_t)env * 6);
-    }
     wave_lds_sync();
+}
+
+// both halves back to back (the inline reset)
+template <int LPE>
+__device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, int16_t *scr, int lane, int a, int env,
+                                                             bool env_ok, bool do_reset, int N, const uint64_t *rng_src) {
+    int pop = 0;
+    const bool ok = draw_stage_a<LPE>(p, scr, lane, a, env, env_ok, do_reset, N, nullptr, PcgPre{false, {}, 0, {}, {}}, rng_src, pop);
+    draw_stage_b<LPE>(scr, lane, a, ok, N, pop);
     return ok;
 }
 
@@ -1387,17 +1512,20 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
     if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
         // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False).  A pre-drawn placement (see
         // kSlotInvalid) IS that draw; otherwise it is made here.
-        const bool slot_ok = do_reset && gballot<LPE>(is_agent && nsg == kSlotInvalid, lane) == 0;
+        const bool slot_ok = do_reset && gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
         const bool draw = do_reset && !slot_ok;
         if (__any(draw)) {
+            // a staged background draw has advanced Params::rng already: the visible stream is in vis_rng then
+            const bool staged = gballot<LPE>(is_agent && a == 0 && slot_word_staged(nsg), lane) != 0;
+            const uint64_t *rng_src = staged ? p.vis_rng : p.rng;
             int16_t *hs = scratch + grp * p.scratch_i16;
             const int16_t *out = hs + sample_out_off_i16(N);
-            const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, nullptr);
+            const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, rng_src);
             if (__any(draw && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
                 int16_t *outs = hs + p.hash_cap;
                 if (draw && !sampled && a == 0) {
                     Pcg g;
-                    pcg_load(g, p.rng + (size_t)env * 6);
+                    pcg_load(g, rng_src + (size_t)env * 6);
                     const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
                     bool stuck = false;
                     for (int k = 0; k < hash_cap; k++) hs[k] = -1;
@@ -1437,13 +1565,12 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
             }
             wave_lds_sync();
         }
-        if (__any(slot_ok)) {
-            if (slot_ok && is_agent) {
-                st.start = nsg & 0xFFFFu;
-                st.goal = nsg >> 16;
-                slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;  // consumed: Params::rng is the visible state again
-            }
+        if (slot_ok && is_agent) {
+            st.start = nsg & 0xFFFFu;
+            st.goal = nsg >> 16;
         }
+        // consumed, or overtaken by the inline draw (staged): Params::rng is the visible stream again
+        if (do_reset && is_agent && nsg != kSlotInvalid) slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;
         if (do_reset) nsg = kSlotInvalid;
     }
     if (do_reset) {
@@ -1702,11 +1829,14 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     bool fast_reset = false, slow_reset = false, subst = false;
     // Everything about episode ends sits behind ONE wave-uniform branch: a step in which no env of the wave finishes
     // (the common case) pays a ballot and a scalar branch for it.
+    // ('unlikely': measured both ways -- laid out inline the episode-end blocks cost every wave more (B1 is reached
+    // 80 cycles later, 5.5 -> 5.7 us synchronised, 6.2 -> 6.4 staggered) than the jumps to the far end of the kernel
+    // cost the waves that take them)
     if (__builtin_expect(__any(do_reset), 0)) {
         if (nsg_lazy && !deterministic && !lifelong)  // (A/B: the slot is only fetched when an env of the wave finishes)
             nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
         bool slot_ok = deterministic;
-        if (!deterministic && !lifelong) slot_ok = gballot<LPE>(is_agent && nsg == kSlotInvalid, lane) == 0;
+        if (!deterministic && !lifelong) slot_ok = gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
 #ifdef MAPF_NO_FAST_RESET  // (A/B builds)
         slot_ok = false;
 #endif
@@ -2086,21 +2216,19 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (__any(done)) {
         const int completed_now = __popcll(gballot<LPE>(is_agent && completed, lane));
         if (done && a == 0) {
-            int4 *acc = reinterpret_cast<int4 *>(p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC);
-            int4 q0 = acc[0], q1 = acc[1], q2 = acc[2];
-            q0.x += 1;                                      // MAPF_ACC_EPISODES
-            q0.y += (term && !trunc) ? 1 : 0;               // MAPF_ACC_SUCCESSES (SuccessRateCallback)
-            q0.z += sc[MAPF_CTR_GOALS_REACHED_TOTAL];       // goals_reached  <- _episode_goals_reached_total
-            q0.w += sc[MAPF_CTR_BLOCKING_COUNT];            // blocking_count <- _episode_blocking_count
-            q1.x += sc[MAPF_CTR_DEADLOCK_EVENTS];           // deadlock_count
-            q1.y += sc[MAPF_CTR_LIVELOCK_EVENTS];           // livelock_count
-            q1.z += sc[MAPF_CTR_DEADLOCK_STEPS];
-            q1.w += sc[MAPF_CTR_LIVELOCK_STEPS];
-            q2.x += completed_now;                          // completion_ratio numerator (_completed_once_arr)
-            q2.y += sc[MAPF_CTR_STEP_COUNT];                // episode length
-            acc[0] = q0;
-            acc[1] = q1;
-            acc[2] = q2;
+            // adds without a return value: nothing waits for them (a load-modify-store here put a memory round trip
+            // into the tail of every wave in which an episode ends)
+            int *acc = p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC;
+            atomicAdd(acc + MAPF_ACC_EPISODES, 1);
+            if (term && !trunc) atomicAdd(acc + MAPF_ACC_SUCCESSES, 1);                  // SuccessRateCallback
+            atomicAdd(acc + MAPF_ACC_GOALS_REACHED, sc[MAPF_CTR_GOALS_REACHED_TOTAL]);  // <- _episode_goals_reached_total
+            atomicAdd(acc + MAPF_ACC_BLOCKING_COUNT, sc[MAPF_CTR_BLOCKING_COUNT]);      // <- _episode_blocking_count
+            atomicAdd(acc + MAPF_ACC_DEADLOCK_COUNT, sc[MAPF_CTR_DEADLOCK_EVENTS]);
+            atomicAdd(acc + MAPF_ACC_LIVELOCK_COUNT, sc[MAPF_CTR_LIVELOCK_EVENTS]);
+            atomicAdd(acc + MAPF_ACC_DEADLOCK_STEPS, sc[MAPF_CTR_DEADLOCK_STEPS]);
+            atomicAdd(acc + MAPF_ACC_LIVELOCK_STEPS, sc[MAPF_CTR_LIVELOCK_STEPS]);
+            atomicAdd(acc + MAPF_ACC_COMPLETED_AGENTS, completed_now);  // completion_ratio numerator (_completed_once_arr)
+            atomicAdd(acc + MAPF_ACC_EPISODE_STEPS, sc[MAPF_CTR_STEP_COUNT]);           // episode length
         }
     }
 
@@ -2205,6 +2333,183 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sliced background draw (K::kSlicedDraw: specialised finite kernels, N = LPE <= 8).  The next episode's placement of
+// an env is drawn by the OBSERVATION WAVE of the env's own workgroup, a third per launch, in the tail of the wave
+// (after its observation stream is out it has ~2 k cycles to spare while the state wave finishes):
+//     slot word 0  kSlotInvalid --[outputs + bounded draws]--> kSlotStaged --[Floyd]--> kSlotStaged2
+//                  --[shuffle + free-cell gather]--> valid placement
+// Intermediate data waits in Params::stage_vals; what a slice needs from memory is requested right after B0 (the env's
+// slot word and hint arrive with the wave's first loads) and is there long before the tail.  Lane layout = the env
+// groups of the step, so every group works on its own env: no picking, no hand-over, and an env is only touched
+// when its MAY_FINISH hint is clear (nobody else reads or writes its stream or slot in this launch, see sampler_wave).
+// ------------------------------------------------------------------------------------------------
+struct DrawReq {
+    uint32_t w0;       // slot word 0 of the group's env
+    int hint;          // its MAY_FINISH hint
+    uint4 r0, r1, r2;  // slice 1: the env's stream
+    int pop;           // free-cell count
+    uint32_t sv[5];    // slices 2..5: stage_vals dwords a + i * LPE
+};
+template <class K, int LPE>
+__device__ __forceinline__ void draw_request_head(const Io &io, int N, int env, DrawReq &d) {
+    d.w0 = slots_of(io.scal, io.B)[(size_t)env * N];
+    d.hint = io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH];
+}
+// after B0: which slice (0 = none) this group runs in this launch; issues the loads it needs
+constexpr int kDrawSlices = 7;
+template <class K, int LPE>
+__device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, int N, int a, int env, bool env_ok, DrawReq &d) {
+    const bool idle = env_ok && d.hint == 0;
+    int stage = 0;
+    if (idle) {
+        const uint32_t w = d.w0;
+        stage = w == kSlotInvalid ? 1 : ((w >= kSlotStaged6 && w <= kSlotStaged) ? (int)(kSlotStaged - w) + 2 : 0);
+    }
+    d.r0 = d.r1 = d.r2 = make_uint4(0, 0, 0, 0);
+    d.pop = 2 * N + 1;
+#pragma unroll
+    for (int i = 0; i < 5; i++) d.sv[i] = 0;
+    if (__any(stage != 0)) {
+        // ONE kind of slice per wave and launch -- the most advanced one present (drains the pipeline; envs at the same
+        // stage run side by side in their groups, the others wait for a later launch).  Without this a wave whose
+        // envs finished in consecutive steps runs all the slices back to back and becomes the launch's long pole.
+        int run = 0;
+#pragma unroll
+        for (int k = 1; k <= kDrawSlices; k++) run = __any(stage == k) ? k : run;
+        if (stage != run) stage = 0;
+        if (stage != 0) d.pop = free_counts_of(io.scal, io.B, N)[env];
+        if (stage == 1) {
+            // (F = 2N, where the first bounded draw consumes nothing, and the test knob never start a lane-parallel draw)
+            if (d.pop <= 2 * N || (p.flags & MAPF_FLAG_SEQUENTIAL_RESET)) stage = 0;
+        }
+        if (stage == 1 || stage == 2) {  // the stream before the draw: the env's own, or (advanced by slice 1) vis_rng
+            const uint64_t *src = stage == 1 ? streams_of(io.scal, io.B, N) : io.vis_rng;
+            const uint4 *rw = reinterpret_cast<const uint4 *>(src + (size_t)env * 6);
+            d.r0 = rw[0];
+            d.r1 = rw[1];
+            d.r2 = rw[2];
+        }
+        if (stage >= 3) {
+            const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                if ((stage == 3 || i < 2) && a + i * LPE < stage_dwords(N)) d.sv[i] = sv[a + i * LPE];
+        }
+    }
+    return stage;
+}
+// the slice itself (tail of the observation wave)
+template <class K, int LPE>
+__device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_t *scratch, int lane, int env, int stage,
+                                           const DrawReq &d) {
+    const int N = K::N(p);
+    const int grp = lane / LPE, a = lane % LPE;
+    int16_t *hs = scratch + grp * p.scratch_i16;
+    uint32_t *raw = reinterpret_cast<uint32_t *>(hs);
+    uint32_t *vals32 = raw + 4 * N + 2;  // vals[] of the group's scratch, as dwords
+    uint16_t *vals = reinterpret_cast<uint16_t *>(vals32);
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(hs + sample_out_off_i16(N));  // out[2N] (int16) as dwords
+    uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
+    uint32_t *slot = slots_of(io.scal, io.B) + (size_t)env * N;
+    if (__any(stage == 1 || stage == 2)) {
+        // ---- raw outputs (jump-ahead), half of them per slice: first the later half, whose last output carries the
+        //      stream state after the draw (the stream advances, vis_rng keeps the visible state), then the earlier half
+        const bool on = stage == 1 || stage == 2;
+        PcgPre pre;
+        pre.have = true;
+        pre.g.shi = (uint64_t)d.r0.x | ((uint64_t)d.r0.y << 32);
+        pre.g.slo = (uint64_t)d.r0.z | ((uint64_t)d.r0.w << 32);
+        pre.g.ihi = (uint64_t)d.r1.x | ((uint64_t)d.r1.y << 32);
+        pre.g.ilo = (uint64_t)d.r1.z | ((uint64_t)d.r1.w << 32);
+        pre.g.has32 = d.r2.x;
+        pre.g.uinteger = d.r2.z;
+        pre.pop = d.pop;
+        pre.ja = *reinterpret_cast<const uint4 *>(&kPcgJumpA[a + 1][0]);
+        pre.js = *reinterpret_cast<const uint4 *>(&kPcgJumpS[a + 1][0]);
+        int pop_unused;
+        // (one kind of slice per wave and launch: `stage` is wave-uniform among the groups that are on)
+        const int qpass = __any(stage == 1) ? 1 : 0;
+        const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, on, on, N, io.vis_rng, pre, p.rng, pop_unused, -1, 1,
+                                          streams_of(io.scal, io.B, N), qpass, sv);
+        if (on && ok && a == 0) slot[0] = qpass == 1 ? kSlotStaged : kSlotStaged2;
+    }
+    if (__any(stage == 3)) {  // ---- bounded draws (Lemire) on the raw outputs
+        const bool on = stage == 3;
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                if (a + i * LPE < 4 * N + 2) raw[a + i * LPE] = d.sv[i];
+        }
+        wave_lds_sync();
+        PcgPre pre;
+        pre.have = true;
+        pre.g.shi = pre.g.slo = pre.g.ihi = pre.g.ilo = 0;
+        pre.g.has32 = pre.g.uinteger = 0;
+        pre.pop = d.pop;
+        pre.ja = pre.js = make_uint4(0, 0, 0, 0);
+        int pop_unused;
+        const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, on, on, N, nullptr, pre, p.rng, pop_unused, -1, 2);
+        if (on) {
+            if (ok) {
+                sv[a] = vals32[a];
+                sv[a + LPE] = vals32[a + LPE];
+            }
+            if (a == 0) slot[0] = ok ? kSlotStaged3 : kSlotStageFailed;
+        }
+    }
+    if (__any(stage == 4 || stage == 5)) {  // ---- Floyd, half per slice; the chosen values replace the draws
+        const bool on = stage == 4 || stage == 5;
+        const int half = __any(stage == 4) ? 0 : 1;
+        if (on) {
+            vals32[a] = d.sv[0];
+            vals32[a + LPE] = d.sv[1];
+        }
+        wave_lds_sync();
+        int c0 = (int)vals[a], c1 = -1;  // (second half: the first half left this lane's chosen value in its place)
+        draw_floyd16<LPE>(hs, lane, a, N, d.pop, c0, c1, half);
+        wave_lds_sync();
+        if (on) {
+            if (half == 0) vals[a] = (uint16_t)c0;
+            else vals[a + LPE] = (uint16_t)c1;
+        }
+        wave_lds_sync();
+        if (on) {
+            sv[a] = vals32[a];  // dwords 0 .. LPE-1 hold the 2N chosen values; the shuffle indices behind them stay
+            if (a == 0) slot[0] = half == 0 ? kSlotStaged4 : kSlotStaged5;
+        }
+    }
+    if (__any(stage == 6)) {  // ---- tail shuffle -> idx[2N]
+        const bool on = stage == 6;
+        if (on) {
+            vals32[a] = d.sv[0];
+            vals32[a + LPE] = d.sv[1];
+        }
+        wave_lds_sync();
+        const int c0 = (int)vals[a], c1 = (int)vals[a + LPE];
+        draw_shuffle16<LPE>(hs, lane, a, N, c0, c1);
+        wave_lds_sync();
+        if (on) {
+            sv[a] = out32[a];  // N dwords = idx[2N]
+            if (a == 0) slot[0] = kSlotStaged6;
+        }
+    }
+    if (__any(stage == 7)) {  // ---- free-cell gather: the slot becomes valid
+        const bool on = stage == 7;
+        if (on) out32[a] = d.sv[0];
+        wave_lds_sync();
+        if (on) {
+            const int16_t *out = hs + sample_out_off_i16(N);
+            const int HW = io.H * io.W;
+            const uint16_t *fc = io.free_cells + (size_t)env * HW;
+            const int top = HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+            const uint32_t st = fc[min(max((int)out[a], 0), top)];
+            const uint32_t gl = fc[min(max((int)out[N + a], 0), top)];
+            slot[a] = st | (gl << 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Background sampler: workgroups appended to the k_step grid (blockIdx >= number of env workgroups) whose waves
 // pre-draw the NEXT episode's placement of envs that have none (kSlotInvalid), so that the step which ends the episode
 // finds it ready (step_body: fast reset).  Lane i of sampler wave sw looks at env 64*sw + i; envs in need are then
@@ -2213,10 +2518,18 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
 // No race with the env's own workgroup: an env is only touched when its MAY_FINISH hint (written by the previous
 // step) is clear, i.e. when this launch cannot reset it, so nobody else reads or writes its stream or slot now.
 // ------------------------------------------------------------------------------------------------
+// LDS of a sampler workgroup (nothing of the env workgroups' layout is used): per wave a 4 KiB hand-over area (one
+// 64-byte row per lane) followed by the draw scratch of its G groups.
+constexpr int kSamplerHandover = 64 * 64;
+__host__ __device__ constexpr int sampler_lds_bytes_per_wave(int groups, int scratch_i16) {
+    return kSamplerHandover + ((groups * scratch_i16 * 2 + 15) & ~15);
+}
 template <class K, int LPE>
-__device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, int16_t *scratch, const int sw, const int lane,
+__device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, unsigned char *lds, const int sw, const int lane,
                                              const int sw_row) {
     (void)sw_row;
+    uint4 *pf = reinterpret_cast<uint4 *>(lds);
+    int16_t *scratch = reinterpret_cast<int16_t *>(lds + kSamplerHandover);
     constexpr int G = 64 / LPE;
     const int N = K::N(p);
     const int grp = lane / LPE, a = lane % LPE;
@@ -2229,50 +2542,87 @@ __device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, int1
     // the one path of the launch that has no slack).
     const uint32_t slot0 = slots_of(io.scal, io.B)[(size_t)e_c * N];
     const int hint = io.scal[(size_t)e_c * kScalInts + MAPF_CTR_MAY_FINISH];
-    const uint4 *rw = reinterpret_cast<const uint4 *>(p.rng + (size_t)e_c * 6);
+    const uint4 *rw = reinterpret_cast<const uint4 *>(streams_of(io.scal, io.B, N) + (size_t)e_c * 6);
     const uint4 r0 = rw[0], r1 = rw[1], r2 = rw[2];
-    const int pop_l = p.n_free[e_c];
+    const int pop_l = free_counts_of(io.scal, io.B, N)[e_c];
+    const uint4 ja_l = *reinterpret_cast<const uint4 *>(&kPcgJumpA[a + 1][0]);  // this lane's jump-ahead constants
+    const uint4 js_l = *reinterpret_cast<const uint4 *>(&kPcgJumpS[a + 1][0]);
     // (bitwise: all loads are in flight before any value is looked at)
-    uint64_t need = __ballot((int)in & (int)(slot0 == kSlotInvalid) & (int)(hint == 0));
+    const uint64_t idle_ok = __ballot((int)in & (int)(hint == 0));
+    const uint64_t need_b = idle_ok & __ballot(slot0 == kSlotStaged);   // second half pending
+    const uint64_t need_a = idle_ok & __ballot(slot0 == kSlotInvalid);  // nothing drawn yet
     MAPF_STAMP_SW(1);
 #ifdef MAPF_STAMPS
-    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * kDbgRow + 4] = need ? 1 : 0;
+    if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)sw_row * kDbgRow + 4] = need_b ? 2 : (need_a ? 1 : 0);
 #endif
-    // ONE round per launch: the first G envs in need are served, the others in a later launch (an episode that ends
-    // before its turn draws inline, like any env without a slot).  A wave's work is thereby bounded by one draw, which
-    // hides under the step of the env workgroups even when every env of the batch finished in the same step.
-    if (need) {
+    // ONE round per launch and HALF a draw per round: the first G envs in need are served (second halves first), the
+    // others in a later launch (an episode that ends before its slot is ready draws inline, like any env without
+    // one).  A sampler wave's work per launch is thereby bounded by half a draw -- about a third of an env workgroup's
+    // step -- whatever happened to the batch (e.g. every env finishing in the same step).
+    if (need_a | need_b) {
+        uint64_t nb = need_b, na = need_a;
         int pick = -1;
+        bool is_b = false;
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            if (need) {
-                const int bit = (int)__builtin_ctzll(need);
-                need &= need - 1;
+            uint64_t &m = nb ? nb : na;
+            if (m) {
+                const int bit = (int)__builtin_ctzll(m);
+                const bool from_b = nb != 0;
+                m &= m - 1;
                 pick = (grp == g) ? bit : pick;
+                is_b = (grp == g) ? from_b : is_b;
             }
         }
-        const bool act = pick >= 0;
+        const bool act = pick >= 0, act_a = act && !is_b, act_b = act && is_b;
         const int env = act ? sw * 64 + pick : io.B - 1;
         const int src = act ? pick : lane;  // the lane that fetched the picked env's stream
-        PcgPre pre;
-        pre.have = true;
-        pre.g.shi = (uint64_t)(uint32_t)__shfl((int)r0.x, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r0.y, src, 64) << 32);
-        pre.g.slo = (uint64_t)(uint32_t)__shfl((int)r0.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r0.w, src, 64) << 32);
-        pre.g.ihi = (uint64_t)(uint32_t)__shfl((int)r1.x, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r1.y, src, 64) << 32);
-        pre.g.ilo = (uint64_t)(uint32_t)__shfl((int)r1.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r1.w, src, 64) << 32);
-        pre.g.has32 = (uint32_t)__shfl((int)r2.x, src, 64);
-        pre.g.uinteger = (uint32_t)__shfl((int)r2.z, src, 64);
-        pre.pop = __shfl(pop_l, src, 64);
+        // hand-over through LDS (one 64-byte row per lane: three writes + one, then the picked lane's row back) instead
+        // of a dozen cross-lane shuffles
+        pf[lane * 4] = r0;
+        pf[lane * 4 + 1] = r1;
+        pf[lane * 4 + 2] = make_uint4(r2.x, r2.z, (uint32_t)pop_l, 0u);
+        wave_lds_sync();
+        const uint4 q0 = pf[src * 4], q1 = pf[src * 4 + 1], q2 = pf[src * 4 + 2];
+        const int pop = (int)q2.z;
         int16_t *hs = scratch + grp * p.scratch_i16;
-        const bool ok = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, act, act, N, p.vis_rng, pre);
+        uint32_t *vals32 = reinterpret_cast<uint32_t *>(hs) + 4 * N + 2;  // vals[] of the group's scratch, as dwords
+        uint32_t *stage = p.stage_vals + (size_t)env * stage_dwords(N);
+        if (__any(act_a)) {  // ---- first half: raw outputs + bounded draws -> stage_vals, stream advanced
+            PcgPre pre;
+            pre.have = true;
+            pre.g.shi = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+            pre.g.slo = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+            pre.g.ihi = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+            pre.g.ilo = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+            pre.g.has32 = q2.x;
+            pre.g.uinteger = q2.y;
+            pre.pop = pop;
+            pre.ja = ja_l;
+            pre.js = js_l;
+            int pop_unused;
+            MAPF_STAMP_SW(5);
+            const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, act_a, act_a, N, p.vis_rng, pre, p.rng, pop_unused, sw_row);
+            if (act_a && ok) {
+                for (int k = a; k < 2 * N; k += LPE) stage[k] = vals32[k];
+                if (a == 0) slots_of(io.scal, io.B)[(size_t)env * N] = kSlotStaged;
+            }
+        }
         MAPF_STAMP_SW(2);
-        if (act && ok && a < N) {
-            const int16_t *out = hs + sample_out_off_i16(N);
-            const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
-            const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
-            const uint32_t s = fc[min(max((int)out[a], 0), top)];
-            const uint32_t g = fc[min(max((int)out[N + a], 0), top)];
-            slots_of(io.scal, io.B)[(size_t)env * N + a] = s | (g << 16);
+        if (__any(act_b)) {  // ---- second half: Floyd + shuffle on the staged draws -> the placement
+            if (act_b) {
+                for (int k = a; k < 2 * N; k += LPE) vals32[k] = stage[k];
+            }
+            wave_lds_sync();
+            draw_stage_b<LPE>(hs, lane, a, act_b, N, pop);
+            if (act_b && a < N) {
+                const int16_t *out = hs + sample_out_off_i16(N);
+                const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+                const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+                const uint32_t s = fc[min(max((int)out[a], 0), top)];
+                const uint32_t g = fc[min(max((int)out[N + a], 0), top)];
+                slots_of(io.scal, io.B)[(size_t)env * N + a] = s | (g << 16);
+            }
         }
         wave_lds_sync();
 #ifdef MAPF_STAMPS
@@ -2325,23 +2675,29 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
     // pushed their entry 5 KB down and their first scalar loads behind a taken branch: +0.2 us per step)
     if (__builtin_expect(env0 < 0 || env0 >= io.B, 0)) {  // a sampler workgroup (the host adds them in finite mode
                                                           // with sampled placements)
-        const Lds l = carve_lds(io, lds_raw);
         const int si = K::kSamplerFront ? (int)blockIdx.x : (int)blockIdx.x - main_blocks;
-        // two independent sampler waves per workgroup; the second borrows the (unused here) table region as scratch
-        sampler_wave<K, LPE>(p, io, wv == 0 ? l.scratch : reinterpret_cast<int16_t *>(l.tab), si * kWavesPerWg + wv, lane,
+        // independent sampler waves, each with its own slice of the workgroup's LDS
+        sampler_wave<K, LPE>(p, io, lds_raw + wv * sampler_lds_bytes_per_wave(G, p.scratch_i16), si * kWavesPerWg + wv, lane,
                              main_blocks + si);
         return;
     }
 
-#ifdef MAPF_MAIN_PRIO  // (A/B) env workgroups issue ahead of a sampler wave that shares their SIMD
-    __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
+    // env workgroups issue ahead of a sampler wave that shares their SIMD (both of their waves at the same priority:
+    // ranking state against observation wave was measured and is a loss)
+#ifndef MAPF_MAIN_PRIO
+#define MAPF_MAIN_PRIO 2
 #endif
+    __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
     // Both waves issue their global loads from the preloaded arguments alone, and only then wait for the scalar
     // loads (rest of the arguments, Params) in one batch.
     if (kDual && wv == 1) {
         // ---- observation wave: fetches the obstacle rows for both waves, then builds and streams the observations
         RowRegs rr;
         rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+        DrawReq dreq;
+        const bool d_env_ok = grp < ngroups;
+        const int d_env = d_env_ok ? env0 + grp : io.B - 1;
+        if (K::kSlicedDraw) draw_request_head<K, LPE>(io, N, d_env, dreq);
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
@@ -2349,7 +2705,26 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wg_sync();  // B0: rows visible to the state wave
         MAPF_STAMP_W1(10);
+        int d_stage = 0;
+        if (K::kSlicedDraw) d_stage = draw_request_body<K, LPE>(p, io, N, a, d_env, d_env_ok, dreq);
         if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+        if (K::kSlicedDraw && __builtin_expect(__any(d_stage != 0), 0)) {
+            MAPF_STAMP_W1(21);
+            draw_slice<K, LPE>(p, io, l.scratch, lane, d_env, d_stage, dreq);
+#ifdef MAPF_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MAPF_STAMP_W1(22);
+            {
+                int run = 0;
+                for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
+                if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
+            }
+#endif
+        } else {
+#ifdef MAPF_STAMPS
+            if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = 0;
+#endif
+        }
         return;
     }
 

@@ -75,6 +75,7 @@ struct mapf_engine {
     int *d_n_free = nullptr;
     int *d_err = nullptr;
     int *d_ep_acc = nullptr;
+    uint32_t *d_stage_vals = nullptr;  // [B][2N] bounded draws of a staged background draw (Params::stage_vals)
     uint64_t *d_vis_rng = nullptr;  // [B][6] visible stream state of envs whose placement slot is pending (Params::vis_rng)
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
@@ -314,6 +315,9 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         e->sampler_blocks = sampler_blocks_for(B, step_threads(lpe) / 64);  // leading (specialised kernels) or trailing
     }
 #endif
+    const int special_id = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
+    // the specialised finite kernels with N <= 8 draw in slices inside their observation waves (KFixed::kSlicedDraw)
+    if (special_id && e->sampler_blocks && c.num_agents <= 8) e->sampler_blocks = 0;
 
     Params &p = e->p;
     memset(&p, 0, sizeof(p));
@@ -323,7 +327,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
     p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP);
-    e->special = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
+    e->special = special_id;
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
     p.nearby = c.lock_nearby_manhattan;
@@ -368,6 +372,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
             e->lds_bytes += map_bytes;
         }
     }
+    if (e->sampler_blocks) {  // the sampler workgroups of a k_step launch have their own LDS layout
+        const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
+        if (e->lds_bytes < need) e->lds_bytes = need;
+    }
     if (e->lds_bytes > 64 * 1024) {
         delete e;
         return fail(nullptr, MAPF_ERR_CONFIG, "config needs more than 64 KiB of LDS per wavefront");
@@ -392,15 +400,19 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMalloc(&e->d_agents, BN * sizeof(AgentRec)));
     // env scalars [B][16] followed by the next-episode placement slots [B][N] (slots_of(): the step kernel reaches
     // them from its preloaded arguments)
+    // ... and by the env streams and free-cell counts (streams_of / free_counts_of)
     const size_t scal_bytes = (size_t)B * kScalInts * sizeof(int), slot_bytes = BN * sizeof(uint32_t);
-    HIP_TRY(e, hipMalloc(&e->d_scal, scal_bytes + slot_bytes));
+    HIP_TRY(e, hipMalloc(&e->d_scal, scal_block_bytes(B, N)));
+    e->d_rng = streams_of(e->d_scal, B, N);
+    e->d_n_free = free_counts_of(e->d_scal, B, N);
     HIP_TRY(e, hipMalloc(&e->d_vis_rng, (size_t)B * 6 * sizeof(uint64_t)));
+    HIP_TRY(e, hipMalloc(&e->d_stage_vals, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
+    HIP_TRY(e, hipMemset(e->d_stage_vals, 0, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
+    p.stage_vals = e->d_stage_vals;
     HIP_TRY(e, hipMalloc(&e->d_ring, BN * p.ring_stride * sizeof(int16_t)));
-    HIP_TRY(e, hipMalloc(&e->d_rng, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_rows, (size_t)B * H * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_free_cells, (size_t)B * p.HW * sizeof(uint16_t)));
     HIP_TRY(e, hipMalloc(&e->d_free_rank, (size_t)B * p.HW * sizeof(uint16_t)));
-    HIP_TRY(e, hipMalloc(&e->d_n_free, (size_t)B * sizeof(int)));
     HIP_TRY(e, hipMalloc(&e->d_err, 4 * sizeof(int)));
     HIP_TRY(e, hipMemset(e->d_agents, 0, BN * sizeof(AgentRec)));
     HIP_TRY(e, hipMemset(e->d_scal, 0, scal_bytes));
@@ -434,8 +446,7 @@ int mapf_destroy(mapf_handle e) {
     // best effort: a failing free at teardown is reported through the return code, the handle goes away regardless
     DeviceScope scope(e->cfg.device);  // the caller's current device is restored when this returns (e.g. from __del__)
     hipError_t first = scope.status;
-    void *const bufs[] = {e->d_agents, e->d_scal, e->d_ring, e->d_rng, e->d_rows, e->d_free_cells, e->d_free_rank,
-                          e->d_n_free, e->d_err, e->d_ep_acc, e->d_vis_rng, e->d_params, e->d_dbg};
+    void *const bufs[] = {e->d_agents, e->d_scal, e->d_ring, e->d_rows, e->d_free_cells, e->d_free_rank, e->d_err, e->d_ep_acc, e->d_vis_rng, e->d_stage_vals, e->d_params, e->d_dbg};
     for (void *b : bufs) {
         const hipError_t rc = hipFree(b);
         if (first == hipSuccess) first = rc;
@@ -531,8 +542,8 @@ int mapf_get_state(mapf_handle e, mapf_state *out) {
         HIP_TRY(e, hipMemcpy(vis.data(), e->d_vis_rng, vis.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         HIP_TRY(e, hipMemcpy(slots.data(), e->p.next_sg, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         for (int b = 0; b < B; b++) {
-            bool pending = true;  // (a slot is written and voided as a whole; a partly valid one never outlives a launch)
-            for (int n = 0; n < N; n++) pending = pending && slots[(size_t)b * N + n] != kSlotInvalid;
+            // word 0 tells: kSlotInvalid = no background draw has touched the stream; staged or valid = it is advanced
+            const bool pending = slots[(size_t)b * N] != kSlotInvalid;
             if (pending) memcpy(out->rng_words + (size_t)b * 6, vis.data() + (size_t)b * 6, 6 * sizeof(uint64_t));
         }
     }
@@ -737,6 +748,9 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.info_agent = info_agent;
     io.final_obs = final_obs;
     io.auto_reset = auto_reset;
+    io.stage_vals = e->d_stage_vals;
+    io.free_cells = e->d_free_cells;
+    io.vis_rng = e->d_vis_rng;
     ON_DEVICE(e);
     LAUNCH_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
     return MAPF_OK;

@@ -74,6 +74,30 @@ for k, nme in sub.items():
     v = v[full[:, :, k] > 0]
     if v.size:
         print(f"  sub-stamp {nme:38s} at median {np.median(v):7.0f}  p95 {np.percentile(v, 95):7.0f}")
+# the same sub-stamps for the slowest state wave of each launch (a wave in which an episode ends, typically)
+seq = [0, 1, 16, 2, 19, 3, 4, 5, 17, 18, 6, 20, 7, 8, 9]
+lab = ["loads", "target", "move", "B1", "goal/lock", "pairs", "flush", "rewards", "records", "lock det", "info staged", "info out", "state st", "drain"]
+def deltas(rows):  # rows: [n, ROW]
+    pts = [rows[:, k] if k != 0 else rows[:, 0] for k in seq]
+    return [np.median(pts[i + 1] - pts[i]) for i in range(len(seq) - 1)]
+allw = full.reshape(-1, ROW)
+sloww = np.stack([full[t, slow[t]] for t in range(full.shape[0])])
+if (allw[:, 19] > 0).all():
+    print("  phase (sub-stamps)    " + " ".join(f"{x:>11s}" for x in lab))
+    print("  all waves, median     " + " ".join(f"{x:11.0f}" for x in deltas(allw)))
+    print("  slowest wave / launch " + " ".join(f"{x:11.0f}" for x in deltas(sloww)))
+# sliced background draw in the tail of the observation wave (slot 23 = slice kind run, 21 / 22 = start / end)
+kind = full[:, :, 23]
+if (kind > 0).any():
+    names = {1: "outputs, 2nd", 2: "outputs, 1st", 3: "bounded draws", 4: "Floyd, 1st", 5: "Floyd, 2nd", 6: "shuffle", 7: "gather"}
+    print(f"  observation waves running a draw slice per launch (median): {np.median((kind > 0).sum(axis=1)):.0f} of {blocks}")
+    for k in range(1, 8):
+        m = kind == k
+        if m.any():
+            dur = (full[:, :, 22] - full[:, :, 21])[m]
+            end = (full[:, :, 22] - st[:, :, 0])[m]
+            print(f"    slice {k} ({names[k]:13s}): duration median {np.median(dur):6.0f}  p95 {np.percentile(dur, 95):6.0f};  ends at "
+                  f"{np.median(end):6.0f} (p95 {np.percentile(end, 95):6.0f}) after the state wave's first stamp")
 pre = st[:, :, 0] - full[:, :, 15]
 print(f"  wave entry -> first stamp (scalar loads: kernel arguments + Params): median {np.median(pre):.0f}  p95 {np.percentile(pre, 95):.0f}")
 
@@ -92,5 +116,9 @@ if samp.shape[1]:
         d12 = (samp[:, :, 2] - samp[:, :, 1])[act]
         d23 = (samp[:, :, 3] - samp[:, :, 2])[act]
         d03 = (samp[:, :, 3] - samp[:, :, 0])[act]
+        if (samp[:, :, 8][act] > 0).any():  # first-half sub-stamps: prefetched state fetched (5), outputs (6), bounded draws (7), stream stored (8)
+            seq = [1, 5, 6, 7, 8, 2]
+            parts = [np.median((samp[:, :, seq[i + 1]] - samp[:, :, seq[i]])[act]) for i in range(len(seq) - 1)]
+            print("  first half, median cycles: shfl %.0f | jump-ahead outputs %.0f | bounded draws %.0f | stream store %.0f | stage store %.0f" % tuple(parts))
         print(f"  ACTIVE sampler wave: draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f})  gather+store {np.median(d23):.0f} "
               f"(p95 {np.percentile(d23, 95):.0f})  entry -> slot stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
