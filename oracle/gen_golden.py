@@ -5,7 +5,9 @@ Writes small ``.npz`` fixtures to tests/golden/ -- data only: inputs (grids, RNG
 injected state) and the reference's outputs (observations, rewards, done flags, info, state).
 Also exports the reference's named-grid tables (get_grid.py data) to the package data file.
 
-Usage:  python oracle/gen_golden.py            (regenerates everything, deterministic)
+Usage:  python oracle/gen_golden.py            regenerates everything (deterministic: every env is seeded)
+        python oracle/gen_golden.py --check    regenerates into a temporary directory and compares every array with
+                                               the committed fixtures (exit status 1 on any difference)
 """
 
 from __future__ import annotations
@@ -24,6 +26,7 @@ sys.path.insert(0, HERE)
 import ref_harness as rh  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+NAMED_GRIDS = os.path.join(ROOT, "dl_reference_models_amd", "data", "named_grids.npz")
 INFO_ALL_KEYS = (
     "goals_reached_step", "goals_reached_total", "blocking_count_step", "blocking_count_total",
     "deadlock_step", "livelock_step", "deadlock_event_step", "livelock_event_step",
@@ -368,6 +371,31 @@ def g11_exactly_2n_free_cells():
     save("g11_f_equals_2n_4x6_n3", tr)
 
 
+def g12_lifelong_exactly_2n_free_cells():
+    """Lifelong mode with F == 2N: a respawn has k = F - N - (N - 1) + overlap = 1 + overlap candidates, so whenever
+    no agent stands on another agent's goal rng.integers(1) is a bounded draw with bound 0 that consumes NOTHING
+    (and the episode resets start Floyd at j = 0 like g11).  Connected free cells so that arrivals happen."""
+    n = 3
+    grids = []
+    g = np.ones((4, 5), np.uint8)
+    g[1:3, 1:4] = 0  # 2x3 open block: 6 free cells
+    grids.append(g)
+    g = np.ones((4, 5), np.uint8)
+    g[0, 0:3] = 0
+    g[1, 0] = g[1, 2] = 0
+    g[2, 2] = 0  # a bent corridor, 6 free cells
+    grids.append(g)
+    g = np.ones((4, 5), np.uint8)
+    g[3, 0:5] = 0
+    g[2, 4] = 0  # an L, 6 free cells
+    grids.append(g)
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 1, "steps_per_episode": 25, "lifelong_mapf": True,
+           "include_action_mask_in_obs": True}
+    tr = record_trace(cfg, grids, [900, 901, 902], 120)
+    assert float(tr["info_all"][:, :, 0].sum()) >= 10, "the fixture must contain respawns"
+    save("g12_lifelong_f_equals_2n", tr)
+
+
 def g5_named_and_deterministic():
     """Every named grid with its fixed start/goal table (deterministic), 4 or 2 agents."""
     for name in NAMED:
@@ -439,7 +467,9 @@ def g5_micro_cases():
 
     NO, UP, RT, DN, LT = 0, 1, 2, 3, 4
     open5 = np.zeros((5, 5), np.uint8)
-    base = {"env_name": "synthetic", "sensor_range": 1, "steps_per_episode": 20, "include_action_mask_in_obs": True}
+    # (every case is seeded: the recorded RNG words and the lifelong respawns must not depend on OS entropy)
+    base = {"env_name": "synthetic", "seed": 11, "sensor_range": 1, "steps_per_episode": 20,
+            "include_action_mask_in_obs": True}
     # follow, leader has lower index: both move
     run_case("follow_leader_low", dict(base, num_agents=2), open5, [(2, 2), (2, 1)], [(0, 0), (0, 4)], [[RT, RT]])
     # follow, leader has higher index: follower blocked
@@ -492,10 +522,11 @@ def g5_micro_cases():
     # lifelong: agent standing on its goal at NO_OP also respawns; two respawns in one step
     run_case("lifelong_double", dict(base, num_agents=3, lifelong_mapf=True), open5, [(0, 0), (4, 4), (2, 2)],
              [(0, 1), (4, 3), (2, 2)], [[RT, LT, NO], [NO, NO, NO]])
-    # lifelong with exactly one candidate cell: integers(1) draws nothing (k = 1)
+    # lifelong, one agent on a 1x3 strip: two candidate cells after the old goal is released (k = 2; the k = 1 case,
+    # a bounded draw that consumes nothing, is pinned by the batch fixture g12_lifelong_f_equals_2n)
     tiny = np.array([[0, 0, 0]], np.uint8)
-    run_case("lifelong_k1", dict(base, num_agents=1, lifelong_mapf=True, sensor_range=1), tiny, [(0, 0)], [(0, 1)],
-             [[RT], [RT], [LT]])
+    run_case("lifelong_single_agent_1x3", dict(base, num_agents=1, lifelong_mapf=True, sensor_range=1), tiny, [(0, 0)],
+             [(0, 1)], [[RT], [RT], [LT]])
     np.savez_compressed(os.path.join(GOLDEN, "g5_micro_cases.npz"), **cases)
     print(f"  g5_micro_cases.npz  {os.path.getsize(os.path.join(GOLDEN, 'g5_micro_cases.npz')) / 1024:.1f} KiB "
           f"({len([k for k in cases if k.endswith('.config')])} cases)")
@@ -681,7 +712,7 @@ def export_named_grids():
             data[name + ".starts"] = np.array([s[f"agent_{i}"] for i in range(n)], np.int16)
             data[name + ".goals"] = np.array([g[f"agent_{i}"] for i in range(n)], np.int16)
             break
-    path = os.path.join(ROOT, "dl_reference_models_amd", "data", "named_grids.npz")
+    path = NAMED_GRIDS
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.savez_compressed(path, **data)
     print(f"  named_grids.npz {os.path.getsize(path) / 1024:.1f} KiB")
@@ -695,6 +726,7 @@ def main():
     g2_g3_g4_batches()
     g10_wide_groups()
     g11_exactly_2n_free_cells()
+    g12_lifelong_exactly_2n_free_cells()
     g5_named_and_deterministic()
     g5_micro_cases()
     g5_error_paths()
@@ -705,5 +737,39 @@ def main():
     print(f"total golden size: {sizes / 1024:.0f} KiB")
 
 
+def check() -> int:
+    """Regenerate everything into a temporary directory and compare, array by array, with the committed fixtures
+    (the .npz containers themselves differ: zip members carry timestamps)."""
+    import tempfile
+
+    global GOLDEN, NAMED_GRIDS
+    committed, committed_named = GOLDEN, NAMED_GRIDS
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        GOLDEN, NAMED_GRIDS = os.path.join(tmp, "golden"), os.path.join(tmp, "named_grids.npz")
+        main()
+        pairs = [(os.path.join(GOLDEN, f), os.path.join(committed, f)) for f in sorted(os.listdir(GOLDEN))]
+        pairs.append((NAMED_GRIDS, committed_named))
+        extra = sorted(set(os.listdir(committed)) - set(os.listdir(GOLDEN)))
+        bad += [f"{f}: committed but not generated" for f in extra if f.endswith(".npz")]
+        for new, old in pairs:
+            name = os.path.basename(new)
+            if not os.path.exists(old):
+                bad.append(f"{name}: generated but not committed")
+                continue
+            with np.load(new, allow_pickle=False) as a, np.load(old, allow_pickle=False) as b:
+                if sorted(a.files) != sorted(b.files):
+                    bad.append(f"{name}: different arrays {sorted(set(a.files) ^ set(b.files))[:6]}")
+                    continue
+                for k in a.files:
+                    if a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or not np.array_equal(a[k], b[k]):
+                        bad.append(f"{name}: array {k} differs")
+    GOLDEN, NAMED_GRIDS = committed, committed_named
+    for line in bad:
+        print("MISMATCH", line)
+    print("golden fixtures reproduce exactly" if not bad else f"{len(bad)} mismatches")
+    return 1 if bad else 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(check() if "--check" in sys.argv else main())

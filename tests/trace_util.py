@@ -263,13 +263,13 @@ BATCH_FIXTURES = [
     "g4b_lifelong_5x9_n10", "g7_c1_10x10_n2", "g8_sr0_nolock_4x5_n3", "g8_sr4_3x4_n1", "g8_widewin_5x5_n5",
     "g5_named_1_1", "g5_named_1_2", "g5_named_1_3", "g5_named_1_4", "g5_named_2_1", "g5_named_2_2", "g5_named_3_1",
     "g5_named_2_1_b", "g5_det_lifelong_1_4", "g10_n20_finite_12x12", "g10_n40_lifelong_11x13",
-    "g11_f_equals_2n_4x6_n3",
+    "g11_f_equals_2n_4x6_n3", "g12_lifelong_f_equals_2n",
 ]
 
 MICRO_CASES = [
     "follow_leader_low", "follow_leader_high", "swap", "cycle4", "contention", "oob_obstacle", "both_reach",
     "staggered_reach", "truncation", "blocking_pressure", "deadlock_on_goal_blocker", "deadlock_not_sticky",
-    "livelock_oscillation", "lifelong_respawn", "lifelong_double", "lifelong_k1",
+    "livelock_oscillation", "lifelong_respawn", "lifelong_double", "lifelong_single_agent_1x3",
 ]
 
 
