@@ -2796,9 +2796,39 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
 // between B2 and the next B1), so the state wave runs up to one step ahead and the two waves overlap across step
 // boundaries.  Wide groups (the single-buffered LDS cell map) run this kernel with one wave: dual_many_for().
 // ------------------------------------------------------------------------------------------------
+// Device-side action source of the fused kernel (mapf_step_many_sampled): the reference benchmark's masked-random
+// policy (scripts/benchmark_multi_agent_env.py:42-57: uniform over the actions the agent's action mask allows)
+// evaluated in-kernel on the observation the previous step produced, with a counter-based generator (a hash of
+// seed, env, agent and step: reproducible, no state), so that T steps whose actions depend on the observations run in
+// ONE launch.  The actions taken are written to actions_out.
+struct ManyPolicy {
+    const float *obs_in;   // [B][N][L] current observation (mask of the first step); nullptr = actions come from Io::actions
+    int8_t *actions_out;   // [T][B][N]
+    uint64_t seed;
+    int mask_off;          // offset of the 5 mask floats in an observation row
+};
+__device__ __forceinline__ int masked_random_action(uint64_t seed, uint32_t agent_id, uint32_t t, float up, float rt, float dn,
+                                                    float lf) {
+    uint64_t x = seed ^ (((uint64_t)agent_id << 32) | t);  // splitmix64 finalizer
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    const uint32_t bits = 1u | (up > 0.5f ? 2u : 0u) | (rt > 0.5f ? 4u : 0u) | (dn > 0.5f ? 8u : 0u) | (lf > 0.5f ? 16u : 0u);
+    const uint32_t r = (uint32_t)(((x >> 32) * (uint64_t)__popc(bits)) >> 32);  // index among the valid actions
+    int act = 0, seen = 0;
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        const int v = (bits >> d) & 1u;
+        act = (v && seen == (int)r) ? d : act;
+        seen += v;
+    }
+    return act;
+}
+
 template <class K, int LPE, int MW>
 __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
-                                                                 const IoTail tail, const int T, const int obs_mode) {
+                                                                 const IoTail tail, const int T, const int obs_mode,
+                                                                 const ManyPolicy pol) {
     const Params &p = *pp;
     warm_scalar_cache(pp, tail);
     const Io io = MAPF_IO_JOIN;
@@ -2826,6 +2856,9 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
             it.obs = obs_of(t);
             if (it.obs == nullptr) continue;
             obs_wave_step<K, LPE, MW>(p, it, with_parity(l, t), lane, env0, ngroups);
+            // B3 (sampled actions only): the state wave picks the next step's actions from the masks staged above; it
+            // comes after B2 in both waves
+            if (pol.obs_in && t + 1 < T) wg_sync();
         }
         return;
     }
@@ -2862,7 +2895,22 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
         if (io.truncated) it.truncated = io.truncated + (size_t)t * io.B;
         if (io.info_all) it.info_all = io.info_all + (size_t)t * io.B * MAPF_INFO_ALL;
         if (io.info_agent) it.info_agent = io.info_agent + (size_t)t * BN * 2;
-        int act = (int)io.actions[(size_t)t * BN + (size_t)env * N + min(a, N - 1)];
+        int act;
+        if (pol.obs_in) {
+            // the agent's action mask: from the caller's observation before the first step, afterwards from the
+            // observation row the previous step staged in LDS (reset observation included)
+            const float *m;
+            if (t == 0) {
+                m = pol.obs_in + ((size_t)env * N + min(a, N - 1)) * L + pol.mask_off;
+            } else {
+                if (kDual) wg_sync();  // B3
+                m = l.stage + (size_t)(grp * N + min(a, N - 1)) * L + pol.mask_off;
+            }
+            act = masked_random_action(pol.seed, (uint32_t)(env * N + a), (uint32_t)t, m[1], m[2], m[3], m[4]);
+            if (full || is_agent) pol.actions_out[(size_t)t * BN + (size_t)env * N + a] = (int8_t)act;
+        } else {
+            act = (int)io.actions[(size_t)t * BN + (size_t)env * N + min(a, N - 1)];
+        }
         act = (full || is_agent) ? act : 0;
         if (full && !__any(act < 0 || act > 4))
             step_body<K, LPE, MW, true, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc, nsg);

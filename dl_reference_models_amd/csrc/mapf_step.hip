@@ -182,26 +182,26 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 }
 
 template <int LPE, int MW>
-hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
+hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
     LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params,
-                   IO_HEAD_ARGS(io), T, obs_mode);
+                   IO_HEAD_ARGS(io), T, obs_mode, pol);
 }
 
-hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, hipStream_t s) {
+hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
         LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),       \
                        dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,   \
-                       obs_mode);
+                       obs_mode, pol);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
 #define MAPF_CASE(L)                                                               \
     case L:                                                                        \
-        if (e->mask_w == 32) return launch_many_t<L, 32>(e, io, T, obs_mode, s);   \
-        if (e->mask_w == 64) return launch_many_t<L, 64>(e, io, T, obs_mode, s);   \
-        return launch_many_t<L, 128>(e, io, T, obs_mode, s);
+        if (e->mask_w == 32) return launch_many_t<L, 32>(e, io, T, obs_mode, pol, s);   \
+        if (e->mask_w == 64) return launch_many_t<L, 64>(e, io, T, obs_mode, pol, s);   \
+        return launch_many_t<L, 128>(e, io, T, obs_mode, pol, s);
     switch (e->lpe) {
         MAPF_CASE(4)
         MAPF_CASE(8)
@@ -756,12 +756,9 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     return MAPF_OK;
 }
 
-int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
-                   uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream) {
-    if (!e || !actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
-    if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
-    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step_many");
-    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_step_many is not available for the single-agent variant");
+static int step_many_impl(mapf_handle e, int32_t T, const int8_t *actions, const ManyPolicy &pol, float *obs,
+                          int32_t obs_mode, float *rewards, uint8_t *terminated, uint8_t *truncated, float *info_all,
+                          uint8_t *info_agent, void *stream) {
     Io io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;
@@ -790,8 +787,36 @@ int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, 
     io.info_agent = info_agent;
     io.auto_reset = 1;
     ON_DEVICE(e);
-    LAUNCH_TRY(e, dispatch_many(e, io, T, obs_mode, (hipStream_t)stream));
+    LAUNCH_TRY(e, dispatch_many(e, io, T, obs_mode, pol, (hipStream_t)stream));
     return MAPF_OK;
+}
+
+int mapf_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
+                   uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream) {
+    if (!e || !actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
+    if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step_many");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_step_many is not available for the single-agent variant");
+    ManyPolicy pol;
+    memset(&pol, 0, sizeof pol);
+    return step_many_impl(e, T, actions, pol, obs, obs_mode, rewards, terminated, truncated, info_all, info_agent, stream);
+}
+
+int mapf_step_many_sampled(mapf_handle e, int32_t T, const float *obs_in, uint64_t seed, int8_t *actions_out, float *obs,
+                           float *rewards, uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent,
+                           void *stream) {
+    if (!e || !obs_in || !actions_out || !obs || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step_many_sampled");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_step_many_sampled is not available for the single-agent variant");
+    if (!(e->p.flags & MAPF_FLAG_ACTION_MASK))
+        return fail(e, MAPF_ERR_CONFIG, "masked sampling needs the action mask in the observation (include_action_mask_in_obs)");
+    ManyPolicy pol;
+    pol.obs_in = obs_in;
+    pol.actions_out = actions_out;
+    pol.seed = seed;
+    pol.mask_off = e->p.L - 5;  // the mask is the tail of the observation row (MA-env:306-328)
+    return step_many_impl(e, T, actions_out /* unused as input */, pol, obs, 2, rewards, terminated, truncated, info_all,
+                          info_agent, stream);
 }
 
 static CteIo make_cte_io(const mapf_engine *e) {

@@ -283,6 +283,33 @@ class VecReferenceModel:
             ptr(out["terminated"]), ptr(out["truncated"]), ptr(out["info_all"]), ptr(out["info_agent"]), self._stream()))
         return out
 
+    def step_many_sampled(self, T: int, seed: int, obs_in: torch.Tensor | None = None) -> dict:
+        """T fused steps in one launch with the DEVICE-SIDE masked-random policy (the reference benchmark's "masked"
+        mode): every agent picks uniformly among the actions its action mask allows, evaluated in-kernel on the
+        observation of the previous step.  ``obs_in`` [B,N,L] is the current observation (default: the tensor the last
+        ``reset`` / ``step`` returned).  Returns fresh tensors: actions [T,B,N] (what was taken), obs [T,B,N,L], rewards,
+        terminated, truncated, info_all, info_agent."""
+        B, N, Lo = self.num_envs, self.num_agents, self.obs_len
+        dev = self.device
+        src = self._obs if obs_in is None else obs_in.to(device=dev, dtype=torch.float32).contiguous()
+        if tuple(src.shape) != (B, N, Lo):
+            raise ValueError(f"obs_in must have shape {(B, N, Lo)}")
+        out = {
+            "actions": torch.empty((T, B, N), dtype=torch.int8, device=dev),
+            "obs": torch.empty((T, B, N, Lo), dtype=torch.float32, device=dev),
+            "rewards": torch.empty((T, B, N), dtype=torch.float32, device=dev),
+            "terminated": torch.empty((T, B), dtype=torch.uint8, device=dev),
+            "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev),
+            "info_all": torch.empty((T, B, L.INFO_ALL), dtype=torch.float32, device=dev),
+            "info_agent": torch.empty((T, B, N, 2), dtype=torch.uint8, device=dev),
+        }
+        self._check(self._lib.mapf_step_many_sampled(
+            self._h, int(T), C.c_void_p(src.data_ptr()), C.c_uint64(int(seed) & (2**64 - 1)),
+            C.c_void_p(out["actions"].data_ptr()), C.c_void_p(out["obs"].data_ptr()), C.c_void_p(out["rewards"].data_ptr()),
+            C.c_void_p(out["terminated"].data_ptr()), C.c_void_p(out["truncated"].data_ptr()),
+            C.c_void_p(out["info_all"].data_ptr()), C.c_void_p(out["info_agent"].data_ptr()), self._stream()), ValueError)
+        return out
+
     def observe(self) -> torch.Tensor:
         """Observation of every agent from the current state (no state change).  Returns a fresh tensor."""
         out = torch.empty_like(self._obs)

@@ -213,6 +213,18 @@ int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, 
 int mapf_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, float *rewards,
                    uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, void *stream);
 
+/* The same fused launch with a DEVICE-SIDE action source, for loops whose actions depend on the observations: the
+ * masked-random policy of the reference's benchmark (scripts/benchmark_multi_agent_env.py:42-57, mode "masked": every
+ * agent picks uniformly among the actions its action mask allows) evaluated in-kernel, step after step, on the
+ * observation the previous step produced -- obs_in [B][N][L] (device) for the first step.  The generator is
+ * counter-based (a hash of seed, env, agent and step index), so a run is reproducible and has no state; it is NOT
+ * NumPy's stream: the actions taken are returned in actions_out [T][B][N] (device) and replaying them through
+ * mapf_step / mapf_step_many gives the same transitions.  Needs MAPF_FLAG_ACTION_MASK; obs [T][B][N][L] is written for
+ * every step (it is what the policy reads); the other outputs are as in mapf_step_many. */
+int mapf_step_many_sampled(mapf_handle h, int32_t T, const float *obs_in, uint64_t seed, int8_t *actions_out, float *obs,
+                           float *rewards, uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent,
+                           void *stream);
+
 /* ---- single-agent (CTE) sibling env: reference src/environments/reference_model_single_agent.py ("SA-env") ----
  * One policy drives all N agents (gym.Env, MultiDiscrete([5]*N) action).  Create the handle with
  * MAPF_FLAG_SINGLE_AGENT (only MAPF_FLAG_DETERMINISTIC is meaningful besides it; sensor_range and the lock

@@ -516,3 +516,65 @@ def test_goal_seeking_policy_ends_episodes_by_success_at_any_step():
         assert np.array_equal(eng.positions(), orc.positions()) and np.array_equal(eng.goals(), orc.goals()), t
     assert successes > 5 * B
     assert np.array_equal(eng.rng_words(), orc.rng_words())
+
+
+# ---- device-side action source of the fused kernel --------------------------------------------------------------
+@pytest.mark.parametrize("shape", [
+    (512, 32, 32, 8, 0.40, {"steps_per_episode": 40}),                                # specialised, two-wave fused kernel
+    (300, 16, 16, 4, 0.20, {"include_goal_distance": True, "steps_per_episode": 25}),  # runtime-config kernel, ragged wave
+    (50, 9, 9, 5, 0.15, {"steps_per_episode": 13, "sensor_range": 1}),                # N < lanes per env
+    (24, 24, 24, 40, 0.20, {"lifelong_mapf": True, "steps_per_episode": 30}),         # wide groups: single-wave fused kernel
+])
+def test_step_many_sampled_policy_is_masked_uniform_and_replayable(shape):
+    """mapf_step_many_sampled: the actions come from the in-kernel masked-random policy.  (1) every action taken was
+    allowed by the mask of the observation it was picked from (the caller's observation for the first step, the
+    previous step's -- reset observation included -- afterwards); (2) replaying the returned actions through single
+    mapf_step launches on a twin engine gives the same observations, rewards, flags, info and final state; (3) the
+    choice is spread over the valid actions; (4) same seed, same actions."""
+    import torch
+
+    B, H, W, N, density, extra = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "steps_per_episode": 50,
+           "include_action_mask_in_obs": True}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, density, N, base_seed=440_000)
+    seeds = list(range(B))
+    a, b, c = (EngineStepper(grids, cfg, seeds=seeds) for _ in range(3))
+    obs0 = a.env.reset().clone()
+    b.env.reset()
+    c.env.reset()
+    T, L = 70, a.L
+    out = a.env.step_many_sampled(T, seed=1234)
+    acts = out["actions"].cpu().numpy()
+    obs = out["obs"].cpu().numpy()
+    assert acts.min() >= 0 and acts.max() <= 4
+    # (1) validity against the mask the policy saw
+    prev = np.concatenate([obs0.cpu().numpy()[None], obs[:-1]])
+    mask = prev[..., L - 5:] > 0.5  # [T, B, N, 5]
+    assert np.take_along_axis(mask, acts[..., None].astype(np.int64), axis=-1).all()
+    # (3) every action is used, and where several are valid NO_OP is not the only pick
+    assert set(np.unique(acts)) == {0, 1, 2, 3, 4}
+    several = mask.sum(-1) >= 3
+    assert 0.15 < (acts[several] == 0).mean() < 0.5
+    # (2) replay through single steps
+    for t in range(T):
+        r = b.env.step(torch.from_numpy(acts[t]).to(b.env.device), auto_reset=True)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            assert np.array_equal(r[k].cpu().numpy(), out[k][t].cpu().numpy()), (k, t)
+    sa, sb = a.env.get_state(), b.env.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert int(sa["counters"][:, 9].sum()) >= B  # episodes ended (and envs were re-placed) inside the launch
+    # (4) reproducible; another seed differs
+    again = c.env.step_many_sampled(T, seed=1234)["actions"].cpu().numpy()
+    assert np.array_equal(again, acts)
+    a2 = EngineStepper(grids, cfg, seeds=seeds)
+    a2.env.reset()
+    assert not np.array_equal(a2.env.step_many_sampled(T, seed=99)["actions"].cpu().numpy(), acts)
+
+
+def test_step_many_sampled_needs_the_mask_in_the_observation():
+    st = EngineStepper(synth_grids(4, 8, 8, 0.1, 2), {"num_agents": 2, "sensor_range": 1}, seeds=[1, 2, 3, 4])
+    st.env.reset()
+    with pytest.raises(ValueError, match="action mask"):
+        st.env.step_many_sampled(5, seed=1)
