@@ -86,6 +86,16 @@ if (allw[:, 19] > 0).all():
     print("  phase (sub-stamps)    " + " ".join(f"{x:>11s}" for x in lab))
     print("  all waves, median     " + " ".join(f"{x:11.0f}" for x in deltas(allw)))
     print("  slowest wave / launch " + " ".join(f"{x:11.0f}" for x in deltas(sloww)))
+# lifelong respawn sub-stamps (24..27), for the waves that had an arrival in the step
+if (full[:, :, 24] > 0).any():
+    m = full[:, :, 27] > full[:, :, 2]
+    if m.any():
+        seq2 = [2, 24, 25, 26, 27, 3]
+        lab2 = ["move end -> stream + ranks", "bounded draw", "rank fixed point", "cell of rank", "rest of goal logic (incl. further arrivals)"]
+        rows2 = full[m]
+        print(f"  respawn (waves with an arrival: {m.mean() * 100:.0f} % of wave-steps), median cycles (last arrival of the step):")
+        for i, nme in enumerate(lab2):
+            print(f"    {nme:52s} {np.median(rows2[:, seq2[i + 1]] - rows2[:, seq2[i]]):7.0f}")
 # sliced background draw in the tail of the observation wave (slot 23 = slice kind run, 21 / 22 = start / end)
 kind = full[:, :, 23]
 if (kind > 0).any():
