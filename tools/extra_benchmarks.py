@@ -71,6 +71,11 @@ def run(name, over=None, fused_T=100, p=None, tag=None, envs=None, stagger=False
         out[label] = {"T": fused_T, "agent_steps_per_s": b * n * fused_T * 5 / dt, "us_per_step": 1e6 * dt / (fused_T * 5)}
         if mode == 2:
             out[label]["roofline_frac"] = bytes_step / (dt / (fused_T * 5)) / 8e12
+    if cfg.get("include_action_mask_in_obs", False):  # T fused steps with the in-kernel masked-random policy
+        f = lambda: env.step_many_sampled(fused_T, seed=5)
+        f(); f()
+        dt = timed(f, 5)
+        out["fused_sampled_policy"] = {"T": fused_T, "agent_steps_per_s": b * n * fused_T * 5 / dt, "us_per_step": 1e6 * dt / (fused_T * 5)}
     env.poll_error()
     st = env.get_state()["counters"]
     out["episodes_finished"] = int(st[:, 9].sum())

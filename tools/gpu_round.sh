@@ -34,6 +34,6 @@ for f in ("bench_share2", "bench_strong1"):
     except Exception as e: print(f, "unreadable", e)
 for line in open('$O/extra.jsonl'):
     d = json.loads(line)
-    print('%-60s single %.2f us  fused %.2f us  fused-last %.2f us' % (d['workload'], d['single_step_per_launch']['us_per_step'], d['fused_obs_every_step']['us_per_step'], d['fused_obs_last_only']['us_per_step']))
+    print('%-60s single %.2f us  fused %.2f us  fused-last %.2f us  fused-sampled %s' % (d['workload'], d['single_step_per_launch']['us_per_step'], d['fused_obs_every_step']['us_per_step'], d['fused_obs_last_only']['us_per_step'], ('%.2f us' % d['fused_sampled_policy']['us_per_step']) if 'fused_sampled_policy' in d else '-'))
 PY
 fi
