@@ -34,11 +34,28 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+STAMP_PATH = SO_PATH + ".srchash"  # digest of what the library was built from (next to it, git-ignored like the .so)
+
+
+def source_digest() -> str:
+    """SHA-256 over the sources, headers, flags and this recipe: the library is current iff its stamp equals this
+    (modification times say nothing -- a copied or checked-out tree can carry a newer-looking stale library)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in SOURCES + DEVICE_INCLUDES + HEADERS:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not os.path.exists(SO_PATH):
+    if not os.path.exists(SO_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(SO_PATH)
-    return any(os.path.getmtime(f) > t for f in SOURCES + DEVICE_INCLUDES + HEADERS + [os.path.abspath(__file__)])
+    with open(STAMP_PATH) as fh:
+        return fh.read().strip() != source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -47,7 +64,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [find_hipcc(), *HIPCC_FLAGS, "-I", os.path.join(ROOT, "include"), "-o", SO_PATH, *SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
+    digest = source_digest()
     subprocess.run(cmd, check=True)
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(digest + "\n")
     return SO_PATH
 
 

@@ -161,3 +161,14 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "mapf_oracle" not in text and "from oracle" not in text, f
     assert "oracle" not in open(os.path.join(ROOT, "scripts", "benchmark_multi_agent_env.py")).read()
+
+
+def test_shipped_library_was_built_from_the_current_sources():
+    """The in-tree libmapfstep.so carries a digest of the sources / flags it was built from (build.py); a library
+    that does not match the tree would make every GPU result a statement about some other code."""
+    from dl_reference_models_amd import build as hip_build
+
+    if not os.path.exists(hip_build.SO_PATH):
+        pytest.skip("library not built yet (build() does it)")
+    assert os.path.exists(hip_build.STAMP_PATH), "libmapfstep.so without a source digest: rebuild it with build.py"
+    assert not hip_build.is_stale(), "libmapfstep.so is older than its sources: run python -m dl_reference_models_amd.build"
