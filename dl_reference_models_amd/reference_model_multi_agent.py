@@ -160,21 +160,17 @@ class ReferenceModel(MultiAgentEnv):
         return comps
 
     def _build_obs_layout(self):
-        lows, highs, slices, start = [], [], {}, 0
+        """Flat observation space and the slice of each component in it (the order of MA-env:306-328)."""
+        names, lows, highs = [], [], []
         for name, space in self._build_obs_component_spaces():
-            if isinstance(space, MultiBinary):
-                size = int(np.prod(space.shape))
-                lo, hi = np.zeros(size, np.float32), np.ones(size, np.float32)
-            else:
-                lo = np.asarray(space.low, np.float32).reshape(-1)
-                hi = np.asarray(space.high, np.float32).reshape(-1)
-            slices[name] = slice(start, start + lo.size)
-            start += lo.size
-            lows.append(lo)
-            highs.append(hi)
-        space = Box(low=np.concatenate(lows).astype(np.float32), high=np.concatenate(highs).astype(np.float32),
-                    dtype=np.float32)
-        return space, slices
+            size = int(np.prod(space.shape))
+            binary = isinstance(space, MultiBinary)
+            names.append((name, size))
+            lows.append(np.zeros(size, np.float32) if binary else np.asarray(space.low, np.float32).ravel())
+            highs.append(np.ones(size, np.float32) if binary else np.asarray(space.high, np.float32).ravel())
+        ends = np.cumsum([size for _, size in names])
+        slices = {name: slice(int(end - size), int(end)) for (name, size), end in zip(names, ends)}
+        return Box(low=np.concatenate(lows), high=np.concatenate(highs), dtype=np.float32), slices
 
     # ---- device <-> host mirror -------------------------------------------------------------------
     def _pull(self):
@@ -306,18 +302,17 @@ class ReferenceModel(MultiAgentEnv):
         return row[self._obs_slices["local_obs"]].astype(np.uint8).reshape(self._view_side, self._view_side)
 
     def get_action_mask(self, obs):
-        """Mask [no-op, up, right, down, left] from a local observation (MA-env:749-773)."""
+        """[no-op, up, right, down, left] from a local observation: a move is allowed iff the neighbouring window cell
+        exists and holds a traversable code (MA-env:749-773).  (step() / reset() take the mask the kernel computed.)"""
+        obs = np.asarray(obs)
+        c = self.sensor_range
+        open_cell = np.isin(obs, self.TRAVERSABLE_LOCAL_VALUES)
         mask = np.zeros(self._action_mask_space.shape, dtype=self._action_mask_space.dtype)
         mask[NO_OP] = 1
-        x = y = self.sensor_range
-        if x > 0 and obs[x - 1, y] in self.TRAVERSABLE_LOCAL_VALUES:
-            mask[UP] = 1
-        if y < obs.shape[1] - 1 and obs[x, y + 1] in self.TRAVERSABLE_LOCAL_VALUES:
-            mask[RIGHT] = 1
-        if x < obs.shape[0] - 1 and obs[x + 1, y] in self.TRAVERSABLE_LOCAL_VALUES:
-            mask[DOWN] = 1
-        if y > 0 and obs[x, y - 1] in self.TRAVERSABLE_LOCAL_VALUES:
-            mask[LEFT] = 1
+        for action, (dr, dc) in ((UP, (-1, 0)), (RIGHT, (0, 1)), (DOWN, (1, 0)), (LEFT, (0, -1))):
+            r, q = c + dr, c + dc
+            if 0 <= r < obs.shape[0] and 0 <= q < obs.shape[1]:
+                mask[action] = int(open_cell[r, q])
         return mask
 
     def _get_goal_delta(self, agent_id: str) -> np.ndarray:

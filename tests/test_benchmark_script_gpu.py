@@ -51,3 +51,12 @@ def test_vectorized_modes_and_throughput_assertion(tmp_path):
     with pytest.raises(AssertionError, match="below required"):
         mod.main(["--num-envs", "8", "--steps", "50", "--warmup-steps", "5", "--modes", "random", "--output-dir",
                   str(tmp_path), "--assert-min-steps-per-s", "1e15"])
+
+
+def test_fused_masked_mode_runs_the_policy_in_the_kernel(tmp_path):
+    """--num-envs 256 --modes masked --fused 25: every launch advances 25 steps with the in-kernel masked-random policy."""
+    mod = _cli()
+    res = mod.main(["--env-name", "ReferenceModel-2-1", "--num-agents", "4", "--modes", "masked", "--steps", "500",
+                    "--warmup-steps", "50", "--num-envs", "256", "--fused", "25", "--output-dir", str(tmp_path)])
+    assert res[0]["mode"] == "masked" and res[0]["fused_steps_per_launch"] == 25 and res[0]["steps"] == 500
+    assert res[0]["episodes_completed"] >= 256 * 4  # 500 steps of 100-step episodes: every env finished at least 4
