@@ -74,6 +74,13 @@ def launch_ranks(args) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    if not args.share_gpu:
+        import torch  # (counting devices does not initialise the GPU)
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
+            return 1
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
@@ -81,16 +88,38 @@ def launch_ranks(args) -> int:
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies early (bad device, OOM) would leave the others waiting in the rendezvous for ever: watch all of
+    # them, and when one fails stop the rest (by pid) and fail
+    import threading
+
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = next(((r, c) for r, c in enumerate(codes) if c not in (None, 0)), None)
+        if failed or all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=20)
+    out = b"".join(c for c in out_chunks if c)
     for line in out.decode().splitlines():  # rank 0's stdout may also carry library chatter (gloo prints there)
         if line.startswith("{"):
             print(line, flush=True)
         elif line.strip():
             print(line, file=sys.stderr)
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+    if failed:
+        print(f"[bench] rank {failed[0]} exited with status {failed[1]}; the other ranks were stopped", file=sys.stderr)
         return 1
     return 0
 

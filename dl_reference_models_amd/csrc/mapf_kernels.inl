@@ -2710,6 +2710,9 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
         if (K::kSlicedDraw && __builtin_expect(__any(d_stage != 0), 0)) {
             MAPF_STAMP_W1(21);
+#ifdef MAPF_SLICE_PRIO  // (A/B) the background slice yields issue slots to the waves that are still stepping
+            __builtin_amdgcn_s_setprio(MAPF_SLICE_PRIO);
+#endif
             draw_slice<K, LPE>(p, io, l.scratch, lane, d_env, d_stage, dreq);
 #ifdef MAPF_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -172,3 +172,17 @@ def test_shipped_library_was_built_from_the_current_sources():
         pytest.skip("library not built yet (build() does it)")
     assert os.path.exists(hip_build.STAMP_PATH), "libmapfstep.so without a source digest: rebuild it with build.py"
     assert not hip_build.is_stale(), "libmapfstep.so is older than its sources: run python -m dl_reference_models_amd.build"
+
+
+def test_bench_refuses_more_gpus_than_the_node_has_instead_of_hanging():
+    """`python bench.py --gpus N` starts its own ranks; asked for more GPUs than are visible it must fail at once with
+    a message (ranks waiting in the rendezvous for a rank that died would otherwise hang the run)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k != "RANK"})
+    assert r.returncode == 1 and "exposes" in r.stderr and r.stdout.strip() == ""
