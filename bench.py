@@ -46,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--pre-roll", type=int, default=-1,
+                    help="untimed steps run when the staggered episode phases are set up, before warmup "
+                         "(default: one episode length; 0 = measure the start-up transient)")
     ap.add_argument("--workload", default=None, help="one of dl_reference_models_amd.workloads.WORKLOADS")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the workload's envs per GPU; strong: --total-envs split over the GPUs")
@@ -307,6 +310,13 @@ def worker(args) -> int:
         run_plain(3)  # code object resident before any capture
         torch.cuda.synchronize(device)
         pl_w, pl_t = plan(args.warmup), plan(args.steps)  # capture happens here, outside the timed region
+        # pre-roll (state preparation, like the reset above; not warmup and not timed; reported in config): by
+        # default one episode length of steps straight before the warmup, so that a SHORT timed window (the driver's
+        # --steps 20 is 0.12 ms of GPU time) sees the steady state of a long run -- every env has been through a reset
+        # since its phase was set, the placements of the episodes ending in the window have been pre-drawn in the
+        # background -- and a GPU that has been busy, instead of the start-up transient after the idle of the capture
+        pre = args.pre_roll if args.pre_roll >= 0 else spe
+        run_steps(pre, plan(pre))
         run_steps(args.warmup, pl_w)
         fence()
         ep0 = int(env.episode_sums()[L.ACC_EPISODES])
@@ -387,6 +397,7 @@ def worker(args) -> int:
             "steps_per_episode": spe, "lock_metrics": True, "auto_reset": "in-kernel",
             "episode_phases": "staggered" if "staggered" in legs else "synchronised",
             "resets_in_timed_region": head["resets"],
+            "pre_roll_steps": args.pre_roll if args.pre_roll >= 0 else spe,
             "actions": "uniform{0..4}, device-resident", "launch": launch,
             "parallelism": f"env-sharded x{world}, no hot-path collective", **env.launch_info(),
         },

@@ -48,7 +48,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps",
+    "mapf_step", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots",
 )
 
 
@@ -152,6 +152,8 @@ def load():
     L.mapf_poll_error.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.mapf_debug_stamps.restype = C.c_int
     L.mapf_debug_stamps.argtypes = [vp, vp, i32]
+    L.mapf_debug_slots.restype = C.c_int
+    L.mapf_debug_slots.argtypes = [vp, vp, vp, vp]
     L.mapf_launch_info.restype = C.c_int
     L.mapf_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L

@@ -1425,8 +1425,11 @@ __device__ __forceinline__ void draw_floyd16(int16_t *scr, int lane, int a, int 
 // _shuffle_int tail shuffle with the precomputed indices vals[2N ..): the permutation fits one 64-bit register as
 // nibbles; every lane applies the swaps to it and then places its chosen values in out[] (group scratch).
 template <int LPE>
-__device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, int N, int c0, int c1) {
+__device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, int N, int c0, int c1, bool on) {
     (void)lane;
+    // `on`: groups that are not drawing run along on whatever their scratch holds; their swap indices are junk, the
+    // nibbles no bijection and inv[] partly unwritten, so they must not store (out[inv[..]] would land in another
+    // group's scratch)
     const int size = 2 * N;
     const uint16_t *vals = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint32_t *>(scr) + 4 * N + 2);
     const uint32_t *j32 = reinterpret_cast<const uint32_t *>(vals + size);  // size is even: 4-byte aligned
@@ -1446,10 +1449,11 @@ __device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, in
     }
     // chosen value t sits at the position x with nibble x == t: scatter through LDS, then every position is read
     uint8_t *inv = reinterpret_cast<uint8_t *>(out + size);  // [16] position of chosen value t
-    for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
+    if (on)
+        for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
     wave_lds_sync();
-    if (a < size) out[inv[a]] = (int16_t)c0;
-    if (a + LPE < size) out[inv[a + LPE]] = (int16_t)c1;
+    if (on && a < size) out[inv[a] & 15] = (int16_t)c0;
+    if (on && a + LPE < size) out[inv[a + LPE] & 15] = (int16_t)c1;
 }
 
 // Second half: Floyd's sampling and the tail shuffle on vals[] (group scratch) -> out[2N] (group scratch).
@@ -1463,7 +1467,7 @@ __device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool
     int c0 = -1, c1 = -1;
     if (size <= 16) {
         draw_floyd16<LPE>(scr, lane, a, N, pop, c0, c1);
-        draw_shuffle16<LPE>(scr, lane, a, N, c0, c1);
+        draw_shuffle16<LPE>(scr, lane, a, N, c0, c1, ok);
     } else {
         for (int k = 0; k < size; k++) {
             const int val = (int)vals[k], j = pop - size + k;
@@ -1714,6 +1718,11 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // state image while the other wave builds, stages and streams out the observations.  With one wave per SIMD
 // (c3: 1024 workgroups on 1024 SIMDs) a step is bound by one wave's dependent-instruction latency, not by
 // bandwidth or issue slots; the split takes the observation (about a third of the instructions) off that path.
+// A/B: 1 = the post-B1 episode-end blocks of the state wave (record image, end-of-body) are laid out inline (the image
+// selects run in every wave) instead of as cold code
+#ifndef MAPF_INLINE_RESET_TAIL
+#define MAPF_INLINE_RESET_TAIL 0
+#endif
 constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSelShift = 3u, kObsWFast = 32u,
                    kObsWReset = 64u,       // the state wave builds this group's reset observation itself, after B2
                    kObsWResetFast = 128u;  // the observation wave builds it (second pass) from entry word z
@@ -2096,7 +2105,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         st.pos = cur;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
         Lane img = st;
-        if (__builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+        if (MAPF_INLINE_RESET_TAIL || __builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
             const uint32_t rs = reset_placement();
             img.start = fast_reset ? (rs & 0xFFFFu) : st.start;
             img.goal = fast_reset ? (rs >> 16) : st.goal;
@@ -2234,7 +2243,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
 
     // ---- auto-reset of finished envs (reference harness loop scripts/benchmark_multi_agent_env.py:89-95:
     //      reset() right after a done step) ------------------------------------------------------------
-    if (__builtin_expect(__any(fast_reset), 0)) {  // placement known: reset() is a register image (MA-env:440-455), the observation wave
+    if (MAPF_INLINE_RESET_TAIL ? __any(fast_reset) : __builtin_expect(__any(fast_reset), 0)) {  // placement known: reset() is a register image (MA-env:440-455), the observation wave
                               // has (or is building) the reset observation
         if (fast_reset) {
             const uint32_t rs = reset_placement();
@@ -2486,7 +2495,7 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         }
         wave_lds_sync();
         const int c0 = (int)vals[a], c1 = (int)vals[a + LPE];
-        draw_shuffle16<LPE>(hs, lane, a, N, c0, c1);
+        draw_shuffle16<LPE>(hs, lane, a, N, c0, c1, on);
         wave_lds_sync();
         if (on) {
             sv[a] = out32[a];  // N dwords = idx[2N]

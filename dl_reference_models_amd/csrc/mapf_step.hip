@@ -973,6 +973,18 @@ int mapf_debug_stamps(mapf_handle e, uint64_t *out, int32_t max_words) {
 #endif
 }
 
+int mapf_debug_slots(mapf_handle e, uint32_t *slots, uint32_t *stage, uint64_t *vis) {
+    if (!e) return MAPF_ERR_CONFIG;
+    ON_DEVICE(e);
+    HIP_TRY(e, hipDeviceSynchronize());
+    const size_t BN = (size_t)e->p.B * e->p.N;
+    if (slots) HIP_TRY(e, hipMemcpy(slots, e->p.next_sg, BN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (stage)
+        HIP_TRY(e, hipMemcpy(stage, e->d_stage_vals, (size_t)e->p.B * stage_dwords(e->p.N) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (vis) HIP_TRY(e, hipMemcpy(vis, e->d_vis_rng, (size_t)e->p.B * 6 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return MAPF_OK;
+}
+
 int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env) {
     if (!e) return MAPF_ERR_CONFIG;
     if (blocks) *blocks = e->blocks;

@@ -260,6 +260,11 @@ int mapf_poll_error(mapf_handle h, void *stream, int32_t *env, int32_t *agent, i
  * s_memtime stamps of the last mapf_step to host uint64 out[workgroups][32]; returns the number of words. */
 int mapf_debug_stamps(mapf_handle h, uint64_t *out /* host */, int32_t max_words);
 
+/* diagnostic: the placement slots [B][N] (mapf_kernels.inl: kSlotInvalid / kSlotStaged*), the staging buffer of the
+ * background draw [B][4N+4] and the visible stream states [B][6] as they are on the device (host outputs, any may be
+ * NULL).  Synchronizes the device. */
+int mapf_debug_slots(mapf_handle h, uint32_t *slots /* host */, uint32_t *stage /* host */, uint64_t *vis /* host */);
+
 /* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes).
  * Returns >= 0: the id of the compile-time specialisation of the step kernel in use (0 = runtime-config kernel). */
 int mapf_launch_info(mapf_handle h, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env);
