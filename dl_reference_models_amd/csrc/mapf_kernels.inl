@@ -1777,6 +1777,24 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     // intended_next (MA-env:514-515) in the (+1,+1) encoding; may lie outside the grid
     const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
     uint32_t cur = old;
+    // Lifelong mode: what a respawn (below) reads from global memory -- the stream state, the free-cell count and the
+    // row-major ranks of my old cell, my target cell and my goal -- is requested here, a whole move phase before it is
+    // needed: a wave in which an agent arrives (most waves of c5, every step) sets the launch's duration, and it used
+    // to start this round trip only after the move.
+    Pcg g_ll;
+    g_ll.shi = g_ll.slo = g_ll.ihi = g_ll.ilo = 0;
+    g_ll.has32 = g_ll.uinteger = 0;
+    int F_ll = 0, rankOld = 0x7FFFFFFF, rankTgt = 0x7FFFFFFF, rankGoal = 0x7FFFFFFF;
+    if (lifelong) {
+        pcg_load(g_ll, p.rng + (size_t)env * 6);
+        F_ll = p.n_free[env];
+        const uint16_t *frank = p.free_rank + (size_t)env * p.HW;
+        if (is_agent) {
+            rankOld = (int)frank[r_old * W + c_old];
+            rankTgt = want ? (int)frank[tr * W + tc] : rankOld;
+            rankGoal = (int)frank[(st.goal >> 8) * W + (st.goal & 255u)];
+        }
+    }
     MAPF_STAMP(16);  // (sub-stamp: target cell known)
     constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
     const bool use_map = MAP_OK && io.use_map;
@@ -1886,19 +1904,19 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (arr_wave) {  // wave-uniform, rare
             const uint64_t garr = gballot<LPE>(on_goal, lane);
             reassigned = garr != 0;
-            // Everything the respawn reads from global memory that does not depend on an earlier respawn of the same
-            // step is fetched here in one round trip (a wave in which an agent arrives sets the launch's duration):
-            // the stream state, the free-cell count and the row-major ranks of my old cell, my new cell and my goal.
-            Pcg g;
-            pcg_load(g, p.rng + (size_t)env * 6);
-            const int F = p.n_free[env];
-            const uint16_t *frank = p.free_rank + (size_t)env * p.HW;
-            const int rankOld = is_agent ? (int)frank[(old >> 8) * W + (old & 255u)] : 0x7FFFFFFF;
-            const int rankCur = is_agent ? (int)frank[(cur >> 8) * W + (cur & 255u)] : 0x7FFFFFFF;
-            int rankGoal = is_agent ? (int)frank[(st.goal >> 8) * W + (st.goal & 255u)] : 0x7FFFFFFF;
-            if (use_map) {  // owner-new ids for the occupancy test below (the full field is ORed in later anyway)
+            // (stream state, free-cell count and ranks were requested before the move phase.)  Everything in the loop
+            // works on ranks: the cell of a goal drawn here is only loaded, never waited for.
+            Pcg g = g_ll;
+            const int F = F_ll;
+            const int rankCur = moved ? rankTgt : rankOld;
+            // index + 1 of the agent standing on my goal cell after (on) / before (oo) its move, 0 = nobody
+            int on = 0, oo = 0;
+            if (use_map) {  // owner-new ids (the full field is ORed in later anyway), then one map read
                 if (is_agent) atomicOr(&mapg[map_index(cur, map_w)], (uint32_t)a + 1u);
                 wave_lds_sync();
+                const uint32_t mw = is_agent ? mapg[map_index(st.goal, map_w)] : 0u;
+                on = (int)(mw & 127u);
+                oo = (int)((mw >> 7) & 127u);
             }
             uint64_t u = fold_groups<LPE>(arr_wave);
             while (u) {  // respawns happen in agent order, each sees the state "at time i" (MA-env:554)
@@ -1906,18 +1924,14 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                 u &= u - 1;
                 const bool gact = (garr >> i) & 1ull;
                 // occupied cells at time i; goals of everybody else (own old goal is released first, MA-env:286-288)
-                const uint32_t P = is_agent ? ((a <= i) ? cur : old) : kIdleCell;
                 const bool Gact = is_agent && a != i;
                 const int rankP = (a <= i) ? rankCur : rankOld;
                 const int rankG = Gact ? rankGoal : 0x7FFFFFFF;
                 bool dup = false;  // my goal cell is also occupied -> count it once
                 if (use_map) {
-                    // one map read: index+1 of the agent standing there after (on) / before (oo) the move
-                    const uint32_t mw = is_agent ? mapg[map_index(st.goal, map_w)] : 0u;
-                    const int on = (int)(mw & 127u), oo = (int)((mw >> 7) & 127u);
                     dup = (on != 0 && on - 1 <= i) || (oo != 0 && oo - 1 > i);
                 } else {
-                    for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(P, q) == st.goal);
+                    for (int q = 0; q < N; q++) dup |= (gshfl<LPE>(rankP, q) == rankGoal);
                 }
                 dup = dup && Gact;
                 const int overlap = __popcll(gballot<LPE>(dup, lane));
@@ -1942,9 +1956,16 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                     y = y2;
                     if (!__any(changed)) break;
                 }
-                if (gact && k > 0 && a == i) {
-                    st.goal = p.free_cells[(size_t)env * p.HW + y];  // MA-env:301-303
-                    rankGoal = y;                                     // the rank of the cell just chosen
+                if (__any(gact && k > 0)) {
+                    // who stands on the chosen cell later in this step (it is free of agents at time i, not after)
+                    const uint64_t bc = gballot<LPE>(is_agent && rankCur == y, lane);
+                    const uint64_t bo = gballot<LPE>(is_agent && rankOld == y, lane);
+                    if (gact && k > 0 && a == i) {
+                        st.goal = p.free_cells[(size_t)env * p.HW + y];  // MA-env:301-303
+                        rankGoal = y;                                     // the rank of the cell just chosen
+                        on = bc ? (int)__builtin_ctzll(bc) + 1 : 0;
+                        oo = bo ? (int)__builtin_ctzll(bo) + 1 : 0;
+                    }
                 }
             }
             if (reassigned && a == 0 && env_ok) pcg_store(g, p.rng + (size_t)env * 6);
@@ -2716,27 +2737,41 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         MAPF_STAMP_W1(10);
         int d_stage = 0;
         if (K::kSlicedDraw) d_stage = draw_request_body<K, LPE>(p, io, N, a, d_env, d_env_ok, dreq);
-        if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
-        if (K::kSlicedDraw && __builtin_expect(__any(d_stage != 0), 0)) {
-            MAPF_STAMP_W1(21);
+        // The background slice runs HERE, in the window in which this wave would only wait for the state wave's moves
+        // (B0 .. B1, about 2700 cycles at c3): at the wave's tail, behind the observation stores, it outlasted the
+        // state wave and set the launch's duration (6.2 against 5.5 us per step at c3 with staggered episodes).  Its
+        // LDS is the draw scratch of its lane group, which the state wave only touches in a slow reset at the end of
+        // its body -- and never for this env in this launch (MAY_FINISH hint).
+#ifndef MAPF_SLICE_EARLY
+#define MAPF_SLICE_EARLY 1  // A/B: 0 = at the tail of the observation wave
+#endif
+        auto run_slice = [&]() {
+            if (K::kSlicedDraw && __builtin_expect(__any(d_stage != 0), 0)) {
+                MAPF_STAMP_W1(21);
 #ifdef MAPF_SLICE_PRIO  // (A/B) the background slice yields issue slots to the waves that are still stepping
-            __builtin_amdgcn_s_setprio(MAPF_SLICE_PRIO);
+                __builtin_amdgcn_s_setprio(MAPF_SLICE_PRIO);
 #endif
-            draw_slice<K, LPE>(p, io, l.scratch, lane, d_env, d_stage, dreq);
+                draw_slice<K, LPE>(p, io, l.scratch, lane, d_env, d_stage, dreq);
+#ifdef MAPF_SLICE_PRIO
+                __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
+#endif
 #ifdef MAPF_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MAPF_STAMP_W1(22);
-            {
-                int run = 0;
-                for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
-                if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
+                MAPF_STAMP_W1(22);
+                {
+                    int run = 0;
+                    for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
+                    if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
+                }
+#endif
+            } else {
+#ifdef MAPF_STAMPS
+                if (K::kSlicedDraw && p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = 0;
+#endif
             }
-#endif
-        } else {
-#ifdef MAPF_STAMPS
-            if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = 0;
-#endif
-        }
+        };
+        if (MAPF_SLICE_EARLY) run_slice();
+        if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+        if (!MAPF_SLICE_EARLY) run_slice();
         return;
     }
 
