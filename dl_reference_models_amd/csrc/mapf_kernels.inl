@@ -251,6 +251,7 @@ struct KRuntime {
     static constexpr bool kFixed = false;
     static constexpr bool kSamplerFront = false;
     static constexpr bool kSlicedDraw = false;
+    static constexpr bool kMapAlways = false;
     __device__ static __forceinline__ int N(const Params &p) { return p.N; }
     __device__ static __forceinline__ int sr(const Params &p) { return p.sr; }
     __device__ static __forceinline__ int V(const Params &p) { return p.V; }
@@ -271,6 +272,10 @@ struct KFixed {
     // the observation wave of the env's own workgroup (draw_slice), no sampler workgroups
     static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && N_ <= 8;
     static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && !kSlicedDraw;
+    // wide groups (N > 16): the specialisation is only used with the LDS cell map (mapf_create falls back to the
+    // runtime-config kernel otherwise), so the all-pairs walk is not compiled in: at N = 64 its unrolled loops were
+    // a third of the code (98 KB against a 64 KB instruction cache) and much of the register pressure
+    static constexpr bool kMapAlways = N_ > 16;
     __device__ static __forceinline__ int N(const Params &) { return N_; }
     __device__ static __forceinline__ int sr(const Params &) { return SR_; }
     __device__ static __forceinline__ int V(const Params &) { return 2 * SR_ + 1; }
@@ -1797,7 +1802,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     }
     MAPF_STAMP(16);  // (sub-stamp: target cell known)
     constexpr bool MAP_OK = LPE >= 32;  // the cell-map path is only built for wide groups (N > 16)
-    const bool use_map = MAP_OK && io.use_map;
+    const bool use_map = MAP_OK && (K::kMapAlways || io.use_map);
     const int map_w = W + 2 * kRowPad;
     uint32_t *mapg = l.map + grp * (H + 2 * kRowPad) * map_w;
     if (use_map) {
@@ -2322,7 +2327,7 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
     const bool is_agent = (w & kObsWAgent) != 0;
     PairOut po;
     constexpr bool MAP_OK = LPE >= 32;
-    if (MAP_OK && io.use_map) {
+    if (MAP_OK && (K::kMapAlways || io.use_map)) {
         const int map_w = io.W + 2 * kRowPad;
         observe<K, LPE, MW, kObsEmit, MAP_OK>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
                                               (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po,
@@ -2376,16 +2381,24 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
 struct DrawReq {
     uint32_t w0;       // slot word 0 of the group's env
     int hint;          // its MAY_FINISH hint
-    uint4 r0, r1, r2;  // slice 1: the env's stream
+    uint4 rq;          // slices 1, 2: the stream the outputs are computed from, 16 bytes each in lanes 0 .. 2 of the group
     int pop;           // free-cell count
-    uint32_t sv[5];    // slices 2..5: stage_vals dwords a + i * LPE
+    uint32_t sv[5];    // slices 3..7: stage_vals dwords a + i * LPE
 };
+// With the wave's first loads: the env's slot word and hint, and -- speculatively, 116 bytes per env and launch, so that
+// a slice starts computing at B0 instead of a memory round trip later (it has to be done by B1) -- the free-cell count,
+// the first two staging dwords of every lane (all that slices 4 .. 7 read) and the visible stream (slice 2).
 template <class K, int LPE>
-__device__ __forceinline__ void draw_request_head(const Io &io, int N, int env, DrawReq &d) {
+__device__ __forceinline__ void draw_request_head(const Io &io, int N, int a, int env, DrawReq &d) {
     d.w0 = slots_of(io.scal, io.B)[(size_t)env * N];
     d.hint = io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH];
+    d.pop = free_counts_of(io.scal, io.B, N)[env];
+    const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
+    d.sv[0] = sv[a];
+    d.sv[1] = sv[a + LPE];
+    d.rq = reinterpret_cast<const uint4 *>(io.vis_rng + (size_t)env * 6)[min(a, 2)];
 }
-// after B0: which slice (0 = none) this group runs in this launch; issues the loads it needs
+// after B0: which slice (0 = none) this group runs in this launch; issues the loads it still needs
 constexpr int kDrawSlices = 7;
 template <class K, int LPE>
 __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, int N, int a, int env, bool env_ok, DrawReq &d) {
@@ -2395,10 +2408,8 @@ __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, 
         const uint32_t w = d.w0;
         stage = w == kSlotInvalid ? 1 : ((w >= kSlotStaged6 && w <= kSlotStaged) ? (int)(kSlotStaged - w) + 2 : 0);
     }
-    d.r0 = d.r1 = d.r2 = make_uint4(0, 0, 0, 0);
-    d.pop = 2 * N + 1;
 #pragma unroll
-    for (int i = 0; i < 5; i++) d.sv[i] = 0;
+    for (int i = 2; i < 5; i++) d.sv[i] = 0;
     if (__any(stage != 0)) {
         // ONE kind of slice per wave and launch -- the most advanced one present (drains the pipeline; envs at the same
         // stage run side by side in their groups, the others wait for a later launch).  Without this a wave whose
@@ -2407,23 +2418,19 @@ __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, 
 #pragma unroll
         for (int k = 1; k <= kDrawSlices; k++) run = __any(stage == k) ? k : run;
         if (stage != run) stage = 0;
-        if (stage != 0) d.pop = free_counts_of(io.scal, io.B, N)[env];
         if (stage == 1) {
             // (F = 2N, where the first bounded draw consumes nothing, and the test knob never start a lane-parallel draw)
             if (d.pop <= 2 * N || (p.flags & MAPF_FLAG_SEQUENTIAL_RESET)) stage = 0;
         }
-        if (stage == 1 || stage == 2) {  // the stream before the draw: the env's own, or (advanced by slice 1) vis_rng
-            const uint64_t *src = stage == 1 ? streams_of(io.scal, io.B, N) : io.vis_rng;
-            const uint4 *rw = reinterpret_cast<const uint4 *>(src + (size_t)env * 6);
-            d.r0 = rw[0];
-            d.r1 = rw[1];
-            d.r2 = rw[2];
+        if (__any(stage == 1)) {  // the stream before the draw is the env's own (slice 2: vis_rng, fetched with the head)
+            const uint4 *rw = reinterpret_cast<const uint4 *>(streams_of(io.scal, io.B, N) + (size_t)env * 6);
+            if (stage == 1) d.rq = rw[min(a, 2)];
         }
-        if (stage >= 3) {
+        if (__any(stage == 3)) {
             const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
 #pragma unroll
-            for (int i = 0; i < 5; i++)
-                if ((stage == 3 || i < 2) && a + i * LPE < stage_dwords(N)) d.sv[i] = sv[a + i * LPE];
+            for (int i = 2; i < 5; i++)
+                if (stage == 3 && a + i * LPE < stage_dwords(N)) d.sv[i] = sv[a + i * LPE];
         }
     }
     return stage;
@@ -2447,12 +2454,13 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         const bool on = stage == 1 || stage == 2;
         PcgPre pre;
         pre.have = true;
-        pre.g.shi = (uint64_t)d.r0.x | ((uint64_t)d.r0.y << 32);
-        pre.g.slo = (uint64_t)d.r0.z | ((uint64_t)d.r0.w << 32);
-        pre.g.ihi = (uint64_t)d.r1.x | ((uint64_t)d.r1.y << 32);
-        pre.g.ilo = (uint64_t)d.r1.z | ((uint64_t)d.r1.w << 32);
-        pre.g.has32 = d.r2.x;
-        pre.g.uinteger = d.r2.z;
+        // (the 48 bytes of the stream sit in lanes 0 .. 2 of the group)
+        pre.g.shi = (uint64_t)gshfl<LPE>(d.rq.x, 0) | ((uint64_t)gshfl<LPE>(d.rq.y, 0) << 32);
+        pre.g.slo = (uint64_t)gshfl<LPE>(d.rq.z, 0) | ((uint64_t)gshfl<LPE>(d.rq.w, 0) << 32);
+        pre.g.ihi = (uint64_t)gshfl<LPE>(d.rq.x, 1) | ((uint64_t)gshfl<LPE>(d.rq.y, 1) << 32);
+        pre.g.ilo = (uint64_t)gshfl<LPE>(d.rq.z, 1) | ((uint64_t)gshfl<LPE>(d.rq.w, 1) << 32);
+        pre.g.has32 = gshfl<LPE>(d.rq.x, 2);
+        pre.g.uinteger = gshfl<LPE>(d.rq.z, 2);
         pre.pop = d.pop;
         pre.ja = *reinterpret_cast<const uint4 *>(&kPcgJumpA[a + 1][0]);
         pre.js = *reinterpret_cast<const uint4 *>(&kPcgJumpS[a + 1][0]);
@@ -2727,11 +2735,11 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         DrawReq dreq;
         const bool d_env_ok = grp < ngroups;
         const int d_env = d_env_ok ? env0 + grp : io.B - 1;
-        if (K::kSlicedDraw) draw_request_head<K, LPE>(io, N, d_env, dreq);
+        if (K::kSlicedDraw) draw_request_head<K, LPE>(io, N, a, d_env, dreq);
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
-        if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
+        if (LPE >= 32 && (K::kMapAlways || io.use_map)) clear_cell_maps<LPE>(io, l.map, lane);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wg_sync();  // B0: rows visible to the state wave
         MAPF_STAMP_W1(10);
@@ -2805,7 +2813,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
     if (kDual) {
         wg_sync();  // B0
     } else {
-        if (LPE >= 32 && io.use_map) clear_cell_maps<LPE>(io, l.map, lane);
+        if (LPE >= 32 && (K::kMapAlways || io.use_map)) clear_cell_maps<LPE>(io, l.map, lane);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wave_lds_sync();
     }
@@ -2929,7 +2937,7 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
     }
 
     for (int t = 0; t < T; t++) {
-        if (LPE >= 32 && io.use_map) {
+        if (LPE >= 32 && (K::kMapAlways || io.use_map)) {
             clear_cell_maps<LPE>(io, l.map, lane);
             wave_lds_sync();
         }

@@ -371,6 +371,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
             e->lds_map_off = e->lds_bytes;
             e->lds_bytes += map_bytes;
         }
+        // the wide specialisations are compiled for the cell-map path only (KFixed::kMapAlways)
+        if (e->special && N > 16 && !e->use_map) e->special = 0;
     }
     if (e->sampler_blocks) {  // the sampler workgroups of a k_step launch have their own LDS layout
         const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
