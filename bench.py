@@ -321,6 +321,8 @@ def worker(args) -> int:
         fence()
         ep0 = int(env.episode_sums()[L.ACC_EPISODES])
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)  # (torch creates the HIP event at its first record: not inside the timed region)
+        ev1.record(stream)
         fence()
         t0 = time.perf_counter()
         ev0.record(stream)
