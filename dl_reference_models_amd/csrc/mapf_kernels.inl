@@ -1474,24 +1474,77 @@ __device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool
         draw_floyd16<LPE>(scr, lane, a, N, pop, c0, c1);
         draw_shuffle16<LPE>(scr, lane, a, N, c0, c1, ok);
     } else {
-        for (int k = 0; k < size; k++) {
-            const int val = (int)vals[k], j = pop - size + k;
-            const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
-            const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
-            if (a == (k & (LPE - 1))) {
-                if (k < LPE) c0 = chosen;
-                else c1 = chosen;
+        // Longer lists (N > 8: up to 128 values at N = 64).  Floyd's sampling and the tail shuffle are sequential as
+        // NumPy writes them, 2N dependent iterations each (40 k cycles of one wave at N = 64, during which the other
+        // 1 023 wait for the launch to end).  With one group per wave (N > 32) both are restated with short chains:
+        if (LPE == 64) {
+            // ---- Floyd.  chosen_k = val_k unless val_k was chosen before, then j_k = pop - size + k.  Only a SUSPECT
+            //      k can hit: one whose value occurred at a smaller index, or lies in the j range (>= pop - size); any
+            //      other k finds chosen_i in {val_i != val_k, j_i > val_k} for all i < k.  Suspects are found with an
+            //      all-pairs pass whose iterations do not depend on each other, and only they (a handful: 2N^2 / F
+            //      expected) run the sequential test, in index order.
+            const int v0 = (int)vals[min(a, size - 1)], v1 = (int)vals[min(a + LPE, size - 1)];
+            const int j0 = (int)vals[size + min(a, size - 2)], j1 = (int)vals[size + min(a + LPE, size - 2)];
+            bool dup0 = false, dup1 = false;
+            for (int q = 0; q < size; q++) {
+                const int x = (int)gshfl<LPE>((uint32_t)(q < LPE ? v0 : v1), q & (LPE - 1));
+                dup0 |= q < a && x == v0;
+                dup1 |= q < a + LPE && x == v1;
             }
-        }
-        if (a < size) out[a] = (int16_t)c0;
-        if (a + LPE < size) out[a + LPE] = (int16_t)c1;
-        wave_lds_sync();
-        if (ok && a == 0) {  // longer index lists are swapped in LDS by one lane
+            c0 = v0;
+            c1 = v1;
+            const bool sus0 = a < size && (dup0 || v0 >= pop - size);
+            const bool sus1 = a + LPE < size && (dup1 || v1 >= pop - size);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint64_t u = __ballot(h == 0 ? sus0 : sus1);
+                while (u) {
+                    const int t = (int)__builtin_ctzll(u), k = t + h * LPE;
+                    u &= u - 1;
+                    const int val = (int)gshfl<LPE>((uint32_t)(h == 0 ? v0 : v1), t);
+                    const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+                    const int chosen = __ballot(hit) != 0 ? pop - size + k : val;
+                    if (a == t) {
+                        if (h == 0) c0 = chosen;
+                        else c1 = chosen;
+                    }
+                }
+            }
+            // ---- tail shuffle: swap(out[i], out[j_i]) for i = size-1 .. 1.  Every lane follows its own two elements
+            //      through the swaps (position p: p == i -> j, p == j -> i); the swap indices come from a broadcast
+            //      that does not depend on the positions, so an iteration's chain is two compares and two selects.
+            //      (A group that is not drawing runs along on junk: only registers, and the stores are guarded.)
+            int p0 = a, p1 = a + LPE;
             for (int i = size - 1; i >= 1; i--) {
-                const int j = (int)vals[size + (size - 1 - i)];
-                const int16_t t = out[j];
-                out[j] = out[i];
-                out[i] = t;
+                const int t = size - 1 - i;
+                const int j = (int)gshfl<LPE>((uint32_t)(t < LPE ? j0 : j1), t & (LPE - 1));
+                const int n0 = p0 == i ? j : (p0 == j ? i : p0);
+                const int n1 = p1 == i ? j : (p1 == j ? i : p1);
+                p0 = n0;
+                p1 = n1;
+            }
+            if (ok && a < size) out[p0 & (2 * LPE - 1)] = (int16_t)c0;
+            if (ok && a + LPE < size) out[p1 & (2 * LPE - 1)] = (int16_t)c1;
+        } else {
+            for (int k = 0; k < size; k++) {
+                const int val = (int)vals[k], j = pop - size + k;
+                const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
+                const int chosen = gballot<LPE>(hit, lane) != 0 ? j : val;
+                if (a == (k & (LPE - 1))) {
+                    if (k < LPE) c0 = chosen;
+                    else c1 = chosen;
+                }
+            }
+            if (a < size) out[a] = (int16_t)c0;
+            if (a + LPE < size) out[a + LPE] = (int16_t)c1;
+            wave_lds_sync();
+            if (ok && a == 0) {  // several groups per wave: the swaps run on the LDS copy, one lane per group
+                for (int i = size - 1; i >= 1; i--) {
+                    const int j = (int)vals[size + (size - 1 - i)];
+                    const int16_t t = out[j];
+                    out[j] = out[i];
+                    out[i] = t;
+                }
             }
         }
     }
@@ -1518,6 +1571,19 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
                                              bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs, uint32_t &nsg,
                                              bool obs_wave_barrier = false) {
     const int N = K::N(p);
+#ifdef MAPF_STAMPS  // (stamps build: slots 24..28 of the workgroup's row time an inline reset)
+#define MAPF_STAMP_RG(k)                                                                                   \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        unsigned long long _t;                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)((env - grp) / (64 / LPE)) * kDbgRow + (k)] = _t;      \
+    } while (0)
+#else
+#define MAPF_STAMP_RG(k) do { } while (0)
+#endif
+    MAPF_STAMP_RG(24);
     if (!(K::flags(p) & MAPF_FLAG_DETERMINISTIC)) {
         // generate_starts_goals MA-env:267-282: idx = rng.choice(F, 2N, replace=False).  A pre-drawn placement (see
         // kSlotInvalid) IS that draw; otherwise it is made here.
@@ -1530,6 +1596,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
             int16_t *hs = scratch + grp * p.scratch_i16;
             const int16_t *out = hs + sample_out_off_i16(N);
             const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, rng_src);
+            MAPF_STAMP_RG(25);
             if (__any(draw && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
                 int16_t *outs = hs + p.hash_cap;
                 if (draw && !sampled && a == 0) {
@@ -1600,7 +1667,9 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
     }
     // Two-wave step kernel: the sampling above only touched the group's scratch, so it ran beside the observation wave;
     // pair table and staging rows are that wave's until it has passed B2.
+    MAPF_STAMP_RG(26);
     if (obs_wave_barrier) wg_sync();  // B2
+    MAPF_STAMP_RG(27);
     if (want_obs) {
         uint4 *tabg = tab + grp * LPE;
         tabg[a] = static_entry(st.pos, st.goal);
@@ -1610,6 +1679,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
                                    is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
         wave_lds_sync();
     }
+    MAPF_STAMP_RG(28);
 }
 
 // zero the wave's cell maps (16-byte LDS stores; in k_step this runs under the latency of the state loads)

@@ -132,3 +132,11 @@ if samp.shape[1]:
             print("  first half, median cycles: shfl %.0f | jump-ahead outputs %.0f | bounded draws %.0f | stream store %.0f | stage store %.0f" % tuple(parts))
         print(f"  ACTIVE sampler wave: draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f})  gather+store {np.median(d23):.0f} "
               f"(p95 {np.percentile(d23, 95):.0f})  entry -> slot stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
+
+# inline resets (reset_groups): stamps 24 entry, 25 placement drawn, 26 state image, 27 past B2, 28 reset observation built
+rg = full[:, :, 24:29]
+have = (rg[:, :, 0] > 0) & (rg[:, :, 4] > rg[:, :, 0])
+if have.any():
+    dd = np.diff(rg[have], axis=1)
+    print(f"  inline resets seen in {int(have.sum())} wave-launches: draw {np.median(dd[:, 0]):.0f}  gather+image {np.median(dd[:, 1]):.0f}  "
+          f"B2 wait {np.median(dd[:, 2]):.0f}  reset observation {np.median(dd[:, 3]):.0f}  (median cycles)")
