@@ -2458,19 +2458,26 @@ struct DrawReq {
 // With the wave's first loads: the env's slot word and hint, and -- speculatively, 116 bytes per env and launch, so that
 // a slice starts computing at B0 instead of a memory round trip later (it has to be done by B1) -- the free-cell count,
 // the first two staging dwords of every lane (all that slices 4 .. 7 read) and the visible stream (slice 2).
-template <class K, int LPE>
+// SPEC = false (the dense build of k_step, WPS != 0: several waves per SIMD hide a round trip, and at 65 536 envs the
+// launch is HBM-bound, where 116 B per env count): only slot word and hint here, the rest once the slice is known.
+template <class K, int LPE, bool SPEC>
 __device__ __forceinline__ void draw_request_head(const Io &io, int N, int a, int env, DrawReq &d) {
     d.w0 = slots_of(io.scal, io.B)[(size_t)env * N];
     d.hint = io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH];
-    d.pop = free_counts_of(io.scal, io.B, N)[env];
-    const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
-    d.sv[0] = sv[a];
-    d.sv[1] = sv[a + LPE];
-    d.rq = reinterpret_cast<const uint4 *>(io.vis_rng + (size_t)env * 6)[min(a, 2)];
+    d.pop = 2 * N + 1;
+    d.sv[0] = d.sv[1] = 0;
+    d.rq = make_uint4(0, 0, 0, 0);
+    if (SPEC) {
+        d.pop = free_counts_of(io.scal, io.B, N)[env];
+        const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
+        d.sv[0] = sv[a];
+        d.sv[1] = sv[a + LPE];
+        d.rq = reinterpret_cast<const uint4 *>(io.vis_rng + (size_t)env * 6)[min(a, 2)];
+    }
 }
 // after B0: which slice (0 = none) this group runs in this launch; issues the loads it still needs
 constexpr int kDrawSlices = 7;
-template <class K, int LPE>
+template <class K, int LPE, bool SPEC>
 __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, int N, int a, int env, bool env_ok, DrawReq &d) {
     const bool idle = env_ok && d.hint == 0;
     int stage = 0;
@@ -2488,6 +2495,7 @@ __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, 
 #pragma unroll
         for (int k = 1; k <= kDrawSlices; k++) run = __any(stage == k) ? k : run;
         if (stage != run) stage = 0;
+        if (!SPEC && stage != 0) d.pop = free_counts_of(io.scal, io.B, N)[env];
         if (stage == 1) {
             // (F = 2N, where the first bounded draw consumes nothing, and the test knob never start a lane-parallel draw)
             if (d.pop <= 2 * N || (p.flags & MAPF_FLAG_SEQUENTIAL_RESET)) stage = 0;
@@ -2496,11 +2504,15 @@ __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, 
             const uint4 *rw = reinterpret_cast<const uint4 *>(streams_of(io.scal, io.B, N) + (size_t)env * 6);
             if (stage == 1) d.rq = rw[min(a, 2)];
         }
-        if (__any(stage == 3)) {
+        if (!SPEC && __any(stage == 2)) {
+            const uint4 *rw = reinterpret_cast<const uint4 *>(io.vis_rng + (size_t)env * 6);
+            if (stage == 2) d.rq = rw[min(a, 2)];
+        }
+        if (__any(stage >= 3)) {
             const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
 #pragma unroll
-            for (int i = 2; i < 5; i++)
-                if (stage == 3 && a + i * LPE < stage_dwords(N)) d.sv[i] = sv[a + i * LPE];
+            for (int i = SPEC ? 2 : 0; i < 5; i++)
+                if ((stage == 3 || (i < 2 && stage > 3)) && a + i * LPE < stage_dwords(N)) d.sv[i] = sv[a + i * LPE];
         }
     }
     return stage;
@@ -2753,11 +2765,16 @@ constexpr bool dual_many_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
 constexpr int step_threads(int lpe) { return dual_for(lpe) ? 128 : 64; }
 constexpr int many_threads(int lpe) { return dual_many_for(lpe) ? 128 : 64; }
 
-// Second launch-bound = minimum waves per SIMD the register budget must allow.  Wide groups: every SIMD has to hold a
+// Second launch bound = minimum waves per SIMD the register budget must allow.  Wide groups: every SIMD has to hold a
 // state wave and an observation wave (c5 launches exactly two waves per SIMD; past 256 registers half of the workgroups
-// wait for a second round: 7.3 -> 11.4 us per step, measured).
-template <class K, int LPE, int MW>
-__global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+// wait for a second round: 7.3 -> 11.4 us per step, measured).  The others: WPS, 0 meaning "no limit".  Without a limit the small-group
+// kernels take ~145 VGPRs (three waves per SIMD), which is right while a launch has at most three waves per SIMD
+// (c3: 8 192 envs = two) -- that build is 0.3 us per step faster there than one squeezed into 128 registers, whose
+// spills sit on the episode-end paths -- and wrong beyond: 16 384 envs of the c3 shape are 4 096 waves, a quarter of
+// them waited for a second round (10.0 us per step against 7.7).  The specialised kernels are therefore built both
+// ways and mapf_create picks by the size of the grid (mapf_engine::dense).
+template <class K, int LPE, int MW, int WPS = 0>
+__global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1))) void k_step(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
                                                             const IoTail tail) {
     MAPF_STAMP_ENTRY();
     const Params &p = *pp;
@@ -2805,7 +2822,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         DrawReq dreq;
         const bool d_env_ok = grp < ngroups;
         const int d_env = d_env_ok ? env0 + grp : io.B - 1;
-        if (K::kSlicedDraw) draw_request_head<K, LPE>(io, N, a, d_env, dreq);
+        if (K::kSlicedDraw) draw_request_head<K, LPE, WPS == 0>(io, N, a, d_env, dreq);
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
@@ -2814,7 +2831,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
         wg_sync();  // B0: rows visible to the state wave
         MAPF_STAMP_W1(10);
         int d_stage = 0;
-        if (K::kSlicedDraw) d_stage = draw_request_body<K, LPE>(p, io, N, a, d_env, d_env_ok, dreq);
+        if (K::kSlicedDraw) d_stage = draw_request_body<K, LPE, WPS == 0>(p, io, N, a, d_env, d_env_ok, dreq);
         // The background slice runs HERE, in the window in which this wave would only wait for the state wave's moves
         // (B0 .. B1, about 2700 cycles at c3): at the wave's tail, behind the observation stores, it outlasted the
         // state wave and set the launch's duration (6.2 against 5.5 us per step at c3 with staggered episodes).  Its
@@ -2862,14 +2879,15 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
 #ifndef MAPF_NSG_MODE
 #define MAPF_NSG_MODE 0  // A/B: 0 slot dword fetched with the state (after it), 1 only when an env finishes, 2 before the state
 #endif
+    constexpr int kNsgMode = WPS != 0 ? 1 : MAPF_NSG_MODE;  // (dense build: 32 B per env and launch less)
     uint32_t nsg = kSlotInvalid;  // pre-drawn placement of the next episode
-    if (MAPF_NSG_MODE == 2) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
+    if (kNsgMode == 2) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     LaneRaw raw;
     lane_issue(io.agents + (size_t)env * N + min(a, N - 1), raw);
     int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
     int sc[12];
     load_scal(io.scal, env, sc);
-    if (MAPF_NSG_MODE == 0) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
+    if (kNsgMode == 0) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     RowRegs rr;
     if (!kDual) rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
     __builtin_amdgcn_sched_barrier(0);  // nothing below may be hoisted between the loads
@@ -2894,9 +2912,9 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : 1)) void k_step
     bool records_stored = false;
     if (full && !__any(act < 0 || act > 4))
         records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg,
-                                                            io.agents + (size_t)env0 * N, MAPF_NSG_MODE == 1);
+                                                            io.agents + (size_t)env0 * N, kNsgMode == 1);
     else
-        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, MAPF_NSG_MODE == 1);
+        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, kNsgMode == 1);
     if (!records_stored) {  // otherwise records and counters left from inside the body
         if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, st);
         else if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);

@@ -31,6 +31,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -54,6 +55,7 @@ struct mapf_engine {
     int lpe = 0;
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
+    int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
     bool cte = false;  // single-agent (CTE) variant
     int col_pad = 0;   // kRowPad when W <= 64 - 2*kRowPad
     int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
@@ -168,13 +170,23 @@ int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     return 0;
 }
 
+// small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
+template <class K, int LPE>
+hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
+    if constexpr (LPE < 32) {
+        if (e->dense)
+            LAUNCH_CHECKED((k_step<K, LPE, 32, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
+                           e->d_params, IO_HEAD_ARGS(io));
+    }
+    LAUNCH_CHECKED((k_step<K, LPE, 32, 0>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
+                   e->d_params, IO_HEAD_ARGS(io));
+}
+
 hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     switch (e->special) {
-#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
-    case ID:                                                                                                        \
-        LAUNCH_CHECKED((k_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),            \
-                       dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE_)), e->lds_bytes, s, e->d_params,    \
-                       IO_HEAD_ARGS(io));
+#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_) \
+    case ID:                                                            \
+        return launch_fixed_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_>(e, io, s);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
@@ -318,6 +330,13 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     const int special_id = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
     // the specialised finite kernels with N <= 8 draw in slices inside their observation waves (KFixed::kSlicedDraw)
     if (special_id && e->sampler_blocks && c.num_agents <= 8) e->sampler_blocks = 0;
+    {   // more than three waves per SIMD in one launch of the step kernel?  (k_step's WPS; 4 SIMDs per compute unit)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
+        const int64_t waves = (int64_t)(e->blocks + e->sampler_blocks) * (step_threads(lpe) / 64);
+        e->dense = waves > (int64_t)3 * 4 * cus;
+        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->dense = atoi(f) != 0;  // test knob: either build on any grid
+    }
 
     Params &p = e->p;
     memset(&p, 0, sizeof(p));

@@ -14,9 +14,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("master,cases,only_n", [(2026, 40, None), (77, 30, 4)])
-def test_short_soak_matches_oracle(master, cases, only_n):
+@pytest.mark.parametrize("master,cases,only_n,dense", [(2026, 40, None, None), (77, 30, 4, None), (4711, 30, None, "1")])
+def test_short_soak_matches_oracle(master, cases, only_n, dense, monkeypatch):
+    """dense = "1": the 128-register build of the specialised step kernels (k_step's WPS = 4: no speculative slice
+    loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per
+    SIMD (MAPF_FORCE_DENSE is read by mapf_create)."""
     from soak_specialized import run_soak
+    if dense is not None:
+        monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
     lines = []
     err = run_soak(master, cases, only_n=only_n, log=lines.append)
     assert err is None, err + "\n" + "\n".join(lines[-8:])
