@@ -148,9 +148,15 @@ enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
-    if (kind == KIND_STEP)
+    if (kind == KIND_STEP) {
+        if constexpr (LPE < 32) {  // both register budgets, as for the specialised kernels (launch_fixed_step)
+            if (e->dense)
+                LAUNCH_CHECKED((k_step<KRuntime, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
+                               e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
+        }
         LAUNCH_CHECKED((k_step<KRuntime, LPE, MW>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
                        e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
+    }
     if (kind == KIND_RESET)
         LAUNCH_CHECKED((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     LAUNCH_CHECKED((k_observe<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
