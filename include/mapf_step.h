@@ -163,6 +163,10 @@ uint32_t mapf_version(void);
 /* flat observation length L for a config (MA-env:214-236): V*V + 2 [+1] [+1] [+5] */
 int32_t mapf_obs_len(const mapf_config *cfg);
 
+/* mapf_create also picks the build of the step kernel by the size of its grid: small-group configurations (at most 16
+ * lanes per env) exist for two register budgets, and a grid of more than three waves per SIMD gets the 128-register
+ * one.  Environment variable MAPF_FORCE_DENSE=0|1 overrides the choice (test knob; results are
+ * identical either way). */
 int mapf_create(const mapf_config *cfg /* host */, mapf_handle *out);
 int mapf_destroy(mapf_handle h);
 const char *mapf_last_error(mapf_handle h); /* h may be NULL: error of the last failed mapf_create */
