@@ -3423,6 +3423,7 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
     X(2, 4, 2, kFlagsHeadline, 8, 16, 2, 1, 4)                              \
     X(3, 64, 2, (kFlagsHeadline | MAPF_FLAG_LIFELONG), 8, 16, 2, 1, 64)     \
     X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8)                            \
-    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)
+    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)                            \
+    X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)  /* the reference's own training setup, main.py:55-67: 16 agents, 7x7 */
 
 }  // namespace

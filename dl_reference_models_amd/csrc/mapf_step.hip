@@ -176,15 +176,20 @@ int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     return 0;
 }
 
+// observation-window mask width of a sensor range (what mapf_create computes into mask_w)
+constexpr int mask_width_for(int sr) {
+    return (2 * sr + 1) * (2 * sr + 1) <= 32 ? 32 : ((2 * sr + 1) * (2 * sr + 1) <= 64 ? 64 : 128);
+}
+
 // small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
-template <class K, int LPE>
+template <class K, int LPE, int MW>
 hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     if constexpr (LPE < 32) {
         if (e->dense)
-            LAUNCH_CHECKED((k_step<K, LPE, 32, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
+            LAUNCH_CHECKED((k_step<K, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
                            e->d_params, IO_HEAD_ARGS(io));
     }
-    LAUNCH_CHECKED((k_step<K, LPE, 32, 0>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
+    LAUNCH_CHECKED((k_step<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
                    e->d_params, IO_HEAD_ARGS(io));
 }
 
@@ -192,7 +197,7 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_) \
     case ID:                                                            \
-        return launch_fixed_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_>(e, io, s);
+        return launch_fixed_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_)>(e, io, s);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
@@ -209,7 +214,7 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
-        LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, 32>),       \
+        LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_)>), \
                        dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,   \
                        obs_mode, pol);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)

@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("master,cases,only_n,dense", [(2026, 40, None, None), (77, 30, 4, None), (4711, 30, None, "1")])
+@pytest.mark.parametrize("master,cases,only_n,dense", [(2026, 40, None, None), (77, 30, 4, None), (4711, 30, None, "1"),
+                                                       (1616, 25, 16, None), (1617, 15, 16, "1")])
 def test_short_soak_matches_oracle(master, cases, only_n, dense, monkeypatch):
     """dense = "1": the 128-register build of the specialised step kernels (k_step's WPS = 4: no speculative slice
     loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per

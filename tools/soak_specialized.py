@@ -7,7 +7,7 @@ also end by success at arbitrary steps), with and without the terminal observati
 positions, goals and generator words every few steps.  tests/test_soak_gpu.py runs a short one (run_soak below); the
 long ones are recorded in DESIGN.md section 2.
 Usage: python tools/soak_specialized.py [master_seed] [cases]
-Environment: SOAK_N=4|8 (one agent count only), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
+Environment: SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
 reset, the A/B), SOAK_ONLY=<case> (run one case of the sequence), SOAK_WATCH=<case>:<env> (print that env's placement slot
 and staging buffer before every step).  Cases are NOT independent on the GPU side: what a kernel finds in LDS depends on
 the launches before it, so a failure is reported with its case number in the sequence."""
@@ -30,6 +30,8 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
             H, W = int(rng.integers(3, 65)), int(rng.integers(3, 65))
         cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2,
                "steps_per_episode": int(rng.choice([1, 2, 3, 5, 9, 17, 40, 100])), "include_action_mask_in_obs": bool(rng.integers(0, 2))}
+        if N == 16:  # specialisation 6: the reference's own training setup (main.py:55-67), sampler workgroups in front
+            cfg.update(sensor_range=3, include_action_mask_in_obs=False)
         B = int(rng.choice([1, 7, 8, 9, 63, 64, 65, 200, 513]))
         density = float(rng.choice([0.0, 0.05, 0.2, 0.4]))
         grids = synth_grids(B, H, W, density, N, base_seed=int(rng.integers(0, 10**6)))
@@ -47,7 +49,7 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
         else:
             kw = {"force_sequential_reset": True} if sequential else {}
             eng = EngineStepper(grids, cfg, seeds=seeds, want_final_obs=want_final, **kw)
-            assert eng.env.launch_info()["specialized_kernel"] in (1, 2, 4, 5), eng.env.launch_info()
+            assert eng.env.launch_info()["specialized_kernel"] in (1, 2, 4, 5, 6), eng.env.launch_info()
             _eq("reset obs", eng.reset(), orc.reset())
         counts = rng.integers(0, cfg["steps_per_episode"], size=B)
         eng.set_step_counts(counts); orc.set_step_counts(counts)
