@@ -109,6 +109,15 @@ def test_engine_vs_oracle_reference_default_obs_layout():
     _vs_oracle(512, 16, 16, 4, 0.20, 220, {"include_action_mask_in_obs": False})
 
 
+def test_engine_vs_oracle_reference_training_setup():
+    """The reference's own training configuration (main.py:55-67: 16 agents, sensor_range 3, mask off): specialisation 6,
+    16-lane groups with the sampler workgroups in front of the grid; also through the runtime-config kernel."""
+    extra = {"sensor_range": 3, "include_action_mask_in_obs": False, "steps_per_episode": 64}
+    stats = _vs_oracle(520, 32, 32, 16, 0.20, 200, extra)
+    assert stats["episodes"] >= 3 * 520
+    _vs_oracle(130, 32, 32, 16, 0.20, 150, dict(extra, force_generic_kernel=True))
+
+
 def test_engine_vs_oracle_c2_1024x16x16x4():
     """BASELINE config 2: 1024 vectorized 16x16 grids, 4 agents, bit-exact check vs CPU."""
     stats = _vs_oracle(1024, 16, 16, 4, 0.20, 320)
@@ -332,6 +341,7 @@ def test_state_snapshot_resumes_bit_exactly_in_a_fresh_engine(extra):
     (300, 16, 16, 4, 0.20, {"include_goal_distance": True}),                        # runtime-config kernel, ragged last wave
     (32, 64, 64, 64, 0.20, {"lifelong_mapf": True, "steps_per_episode": 60}),       # lifelong, respawns + resets inside the loop
     (40, 9, 9, 5, 0.15, {"livelock_window_steps": 30, "deadlock_window_steps": 20, "steps_per_episode": 45}),  # int16 ring path
+    (200, 24, 24, 16, 0.20, {"sensor_range": 3, "include_action_mask_in_obs": False, "steps_per_episode": 40}),  # specialisation 6
 ])
 def test_step_many_equals_repeated_single_steps(shape):
     """mapf_step_many(T) must produce, step for step, what T mapf_step launches produce (and the same final state)."""
