@@ -28,6 +28,7 @@ FLAG_LIFELONG = 16
 FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
 FLAG_SINGLE_AGENT = 256
+FLAG_JIT_SPECIALIZE = 0x10000000
 FLAG_SEQUENTIAL_RESET = 0x20000000
 FLAG_NO_CELL_MAP = 0x40000000
 FLAG_GENERIC_KERNEL = 0x80000000
@@ -48,7 +49,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots",
+    "mapf_step", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
 )
 
 
@@ -152,6 +153,8 @@ def load():
     L.mapf_poll_error.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.mapf_debug_stamps.restype = C.c_int
     L.mapf_debug_stamps.argtypes = [vp, vp, i32]
+    L.mapf_jit_status.restype = C.c_int
+    L.mapf_jit_status.argtypes = [vp, C.POINTER(C.c_char_p)]
     L.mapf_debug_slots.restype = C.c_int
     L.mapf_debug_slots.argtypes = [vp, vp, vp, vp]
     L.mapf_launch_info.restype = C.c_int

@@ -24,7 +24,12 @@
 // flags and lock windows into compile-time constants for the BASELINE.json shapes, KRuntime keeps
 // every other configuration working from the same source.
 
-namespace {
+// MAPF_NS: empty (anonymous namespace) in the library build; the run-time specialisation (mapf_step.hip: jit_specialize)
+// compiles this file once more under a named namespace so that its one instantiation has a linkable name.
+#ifndef MAPF_NS
+#define MAPF_NS
+#endif
+namespace MAPF_NS {
 
 // ------------------------------------------------------------------------------------------------
 // device-side data layout
@@ -270,7 +275,8 @@ struct KFixed {
     static constexpr bool kFixed = true;
     // finite episodes with sampled placements and at most 16 cells to draw: the background draw runs in slices in
     // the observation wave of the env's own workgroup (draw_slice), no sampler workgroups
-    static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && N_ <= 8;
+    // (the slices assume a full group, N = lanes per env: 4 or 8; other small N take the sampler workgroups)
+    static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && (N_ == 4 || N_ == 8);
     static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && !kSlicedDraw;
     // wide groups (N > 16): the specialisation is only used with the LDS cell map (mapf_create falls back to the
     // runtime-config kernel otherwise), so the all-pairs walk is not compiled in: at N = 64 its unrolled loops were
@@ -1173,11 +1179,11 @@ __device__ __forceinline__ void flush_obs_full(const Params &p, const Io &io, fl
         const int n4 = n >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(stage);
         if (K::kFixed) {
-            const int full = n4 >> 6;  // rounds in which all 64 lanes copy
+            const int full = n4 >> 6;  // rounds in which all 64 lanes copy (a compile-time constant here: unrolled whole.
+                                       // It used to be capped at 16 rounds = 4 096 floats per wave, which every prebuilt
+                                       // shape fits; 64 agents with 9x9 windows, compiled at run time, do not)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (r < full) store_obs4(sink, off0 + (unsigned)r * 1024u, s4[r * 64 + lane]);
-            }
+            for (int r = 0; r < full; r++) store_obs4(sink, off0 + (unsigned)r * 1024u, s4[r * 64 + lane]);
             if ((full << 6) + lane < n4) store_obs4(sink, off0 + (unsigned)full * 1024u, s4[(full << 6) + lane]);
         } else {
             for (int k = lane; k < n4; k += 64) store_obs4(sink, off0 + (unsigned)(k - lane) * 16u, s4[k]);

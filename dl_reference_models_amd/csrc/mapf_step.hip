@@ -33,6 +33,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <type_traits>
+#include <dlfcn.h>
+#include <chrono>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +62,9 @@ struct mapf_engine {
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
+    // step kernels compiled for exactly this configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), else null
+    hipFunction_t jit_step = nullptr, jit_many = nullptr;
+    std::string jit_note = "not requested (MAPF_FLAG_JIT_SPECIALIZE)";
     bool cte = false;  // single-agent (CTE) variant
     int col_pad = 0;   // kRowPad when W <= 64 - 2*kRowPad
     int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
@@ -165,7 +174,7 @@ hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t
 // the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
 int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) return 0;
-    const uint32_t cfg_flags = c.flags & ~(MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_SEQUENTIAL_RESET);
+    const uint32_t cfg_flags = c.flags & ~(MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_SEQUENTIAL_RESET | MAPF_FLAG_JIT_SPECIALIZE);
 #define MAPF_MATCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                            \
     if (c.num_agents == N_ && c.sensor_range == SR_ && cfg_flags == (uint32_t)(FLAGS_) &&                             \
         c.deadlock_window_steps == DW_ && c.livelock_window_steps == LW_ && nearby_clamped == NEARBY_ &&           \
@@ -210,7 +219,176 @@ hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode
                    IO_HEAD_ARGS(io), T, obs_mode, pol);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Run-time specialisation (MAPF_FLAG_JIT_SPECIALIZE).  KFixed<...> folds agent count, observation layout, flags and
+// lock windows into the step kernels; the library carries that for the BASELINE.json shapes and the reference's
+// training setup (MAPF_SPECIALIZATIONS).  For any other configuration the same template can be instantiated when
+// the handle is created: hiprtc compiles mapf_kernels.inl (found next to this library) with the one k_step /
+// k_step_many instantiation the handle needs -- 2-3 s each -- and the handle launches those through the module API.
+// hiprtc is loaded with dlopen: no link-time dependency, and every failure (no hiprtc, no source, a compile error)
+// leaves the handle on the runtime-config kernels with the reason in mapf_jit_status().  Compiled modules are kept
+// per process, keyed by the instantiation.
+// ------------------------------------------------------------------------------------------------
+struct Hiprtc {
+    void *lib = nullptr;
+    int (*create)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*add_name)(void *, const char *) = nullptr;
+    int (*compile)(void *, int, const char **) = nullptr;
+    int (*log_size)(void *, size_t *) = nullptr;
+    int (*log)(void *, char *) = nullptr;
+    int (*code_size)(void *, size_t *) = nullptr;
+    int (*code)(void *, char *) = nullptr;
+    int (*lowered)(void *, const char *, const char **) = nullptr;
+    int (*destroy)(void **) = nullptr;
+    bool ok = false;
+};
+const Hiprtc &hiprtc_api() {
+    static Hiprtc h;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+            h.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h.lib) break;
+        }
+        if (!h.lib) return;
+        bool all = true;
+        auto sym = [&](auto &fn, const char *n) {
+            fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h.lib, n));
+            all = all && fn != nullptr;
+        };
+        sym(h.create, "hiprtcCreateProgram");
+        sym(h.add_name, "hiprtcAddNameExpression");
+        sym(h.compile, "hiprtcCompileProgram");
+        sym(h.log_size, "hiprtcGetProgramLogSize");
+        sym(h.log, "hiprtcGetProgramLog");
+        sym(h.code_size, "hiprtcGetCodeSize");
+        sym(h.code, "hiprtcGetCode");
+        sym(h.lowered, "hiprtcGetLoweredName");
+        sym(h.destroy, "hiprtcDestroyProgram");
+        h.ok = all;
+    });
+    return h;
+}
+
+struct JitModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t step = nullptr, many = nullptr;
+    double seconds = 0;
+};
+std::mutex g_jit_mutex;
+std::map<std::string, JitModule> g_jit_cache;  // key: device + the instantiation
+
+// directory of this shared library (the kernel source is installed next to it, the header two levels up)
+std::string library_dir() {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void *>(&mapf_version), &info) || !info.dli_fname) return "";
+    std::string f = info.dli_fname;
+    const size_t k = f.rfind('/');
+    return k == std::string::npos ? "." : f.substr(0, k);
+}
+
+// Tries to give `e` step kernels compiled for its configuration; on any failure e->jit_note says why.
+void jit_specialize(mapf_engine *e) {
+    const mapf_config &c = e->cfg;
+    const int N = c.num_agents, lpe = e->lpe;
+    if (e->cte) { e->jit_note = "single-agent env: runtime-config kernels only"; return; }
+    if (c.flags & MAPF_FLAG_GENERIC_KERNEL) { e->jit_note = "MAPF_FLAG_GENERIC_KERNEL is set"; return; }
+    if (e->special) { e->jit_note = "a prebuilt specialisation matches"; return; }
+    if (lpe != pick_lpe(N)) { e->jit_note = "lanes_per_env overrides the group width"; return; }
+    if (N > 16 && !e->use_map) { e->jit_note = "wide group without the LDS cell map"; return; }
+    const Hiprtc &rt = hiprtc_api();
+    if (!rt.ok) { e->jit_note = "libhiprtc.so could not be loaded"; return; }
+    const std::string dir = library_dir();
+    if (dir.empty() || !std::ifstream(dir + "/mapf_kernels.inl").good()) {
+        e->jit_note = "mapf_kernels.inl not found next to the library (" + dir + ")";
+        return;
+    }
+    char inst[256];
+    snprintf(inst, sizeof inst, "KFixed<%d, %d, %uu, %d, %d, %d, %d>", N, c.sensor_range, (unsigned)e->p.flags & ~MAPF_FLAG_SEQUENTIAL_RESET,
+             c.deadlock_window_steps, c.livelock_window_steps, e->p.nearby, c.lock_min_neighbors);
+    char tail_[64];
+    snprintf(tail_, sizeof tail_, ", %d, %d", lpe, e->mask_w);
+    const int wps = (lpe < 32 && e->dense) ? 4 : 0;
+    const std::string step_expr = std::string("mapfjit::k_step<mapfjit::") + inst + tail_ + ", " + std::to_string(wps) + ">";
+    const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ">";
+    const std::string key = std::to_string(c.device) + "|" + step_expr;
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    auto it = g_jit_cache.find(key);
+    if (it == g_jit_cache.end()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::string src = "#include \"mapf_step.h\"\n#include \"mapf_kernels.inl\"\nnamespace mapfjit {\n";
+        src += std::string("template __global__ void k_step<") + inst + tail_ + ", " + std::to_string(wps) +
+               ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);\n";
+        src += std::string("template __global__ void k_step_many<") + inst + tail_ +
+               ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail, const int, const int, const ManyPolicy);\n}\n";
+        void *prog = nullptr;
+        if (rt.create(&prog, src.c_str(), "mapf_jit.hip", 0, nullptr, nullptr) != 0) { e->jit_note = "hiprtcCreateProgram failed"; return; }
+        rt.add_name(prog, step_expr.c_str());
+        rt.add_name(prog, many_expr.c_str());
+        hipDeviceProp_t prop;
+        std::string arch = "gfx950";
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.gcnArchName[0]) {
+            arch = prop.gcnArchName;
+            arch = arch.substr(0, arch.find(':'));
+        }
+        const std::string o_arch = "--offload-arch=" + arch, o_i1 = "-I" + dir, o_i2 = "-I" + dir + "/../../include";
+        const char *opts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_i1.c_str(), o_i2.c_str(), "-mllvm", "-amdgpu-kernarg-preload-count=16",
+                              "-Wno-unused-value", "-DMAPF_NS=mapfjit"};
+        const int rc = rt.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+        if (rc != 0) {
+            size_t n = 0;
+            rt.log_size(prog, &n);
+            std::string log(n, '\0');
+            if (n) rt.log(prog, &log[0]);
+            e->jit_note = "hiprtc compile error: " + log.substr(0, 600);
+            rt.destroy(&prog);
+            return;
+        }
+        size_t n = 0;
+        rt.code_size(prog, &n);
+        std::vector<char> code(n);
+        rt.code(prog, code.data());
+        const char *step_name = nullptr, *many_name = nullptr;
+        rt.lowered(prog, step_expr.c_str(), &step_name);
+        rt.lowered(prog, many_expr.c_str(), &many_name);
+        JitModule m;
+        hipError_t hs = hipModuleLoadData(&m.mod, code.data());
+        if (hs == hipSuccess && step_name) hs = hipModuleGetFunction(&m.step, m.mod, step_name);
+        if (hs == hipSuccess && many_name) hs = hipModuleGetFunction(&m.many, m.mod, many_name);
+        rt.destroy(&prog);
+        if (hs != hipSuccess || !m.step || !m.many) {
+            e->jit_note = std::string("loading the compiled module failed: ") + hipGetErrorString(hs);
+            if (m.mod) (void)hipModuleUnload(m.mod);
+            return;
+        }
+        m.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        it = g_jit_cache.emplace(key, m).first;
+    }
+    e->jit_step = it->second.step;
+    e->jit_many = it->second.many;
+    char note[128];
+    snprintf(note, sizeof note, "compiled in %.1f s: ", it->second.seconds);
+    e->jit_note = note + step_expr;
+}
+
+hipError_t launch_jit_step(const mapf_engine *e, const Io &io, hipStream_t s) {
+    const Params *pp = e->d_params;
+    IoTail tail = static_cast<const IoTail &>(io);
+    Io h = io;
+    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.col_pad, &tail};
+    return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, step_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
+}
+hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
+    const Params *pp = e->d_params;
+    IoTail tail = static_cast<const IoTail &>(io);
+    Io h = io;
+    ManyPolicy pl = pol;
+    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.col_pad, &tail, &T, &obs_mode, &pl};
+    return hipModuleLaunchKernel(e->jit_many, e->blocks, 1, 1, many_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
+}
+
 hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
+    if (e->jit_many) return launch_jit_many(e, io, T, obs_mode, pol, s);
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
@@ -237,6 +415,7 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
 }
 
 hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
+    if (kind == KIND_STEP && e->jit_step) return launch_jit_step(e, io, s);
     if (kind == KIND_STEP && e->special) return launch_specialized_step(e, io, s);
 #define MAPF_CASE(L)                                                       \
     case L:                                                                \
@@ -341,6 +520,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     const int special_id = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
     // the specialised finite kernels with N <= 8 draw in slices inside their observation waves (KFixed::kSlicedDraw)
     if (special_id && e->sampler_blocks && c.num_agents <= 8) e->sampler_blocks = 0;
+    // a kernel compiled for this configuration (jit_specialize, below) draws in slices as well when N is 4 or 8
+    if (!special_id && !cte && (c.flags & MAPF_FLAG_JIT_SPECIALIZE) && !(c.flags & MAPF_FLAG_GENERIC_KERNEL) &&
+        lpe == pick_lpe(N) && (N == 4 || N == 8))
+        e->sampler_blocks = 0;
     {   // more than three waves per SIMD in one launch of the step kernel?  (k_step's WPS; 4 SIMDs per compute unit)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
@@ -356,7 +539,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.V = 2 * c.sensor_range + 1;
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
-    p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP);
+    p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_JIT_SPECIALIZE);
     e->special = special_id;
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
@@ -419,8 +602,18 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         mapf_destroy(e);
         return rc;
     }
+    if (c.flags & MAPF_FLAG_JIT_SPECIALIZE) {
+        DeviceScope scope(c.device);
+        jit_specialize(e);
+    }
     *out = e;
     return MAPF_OK;
+}
+
+int mapf_jit_status(mapf_handle e, const char **why) {
+    if (!e) return 0;
+    if (why) *why = e->jit_note.c_str();
+    return e->jit_step != nullptr;
 }
 
 static int alloc_device_state(mapf_engine *e) {

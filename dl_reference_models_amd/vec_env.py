@@ -11,6 +11,9 @@ extension keys:
     rng_words       uint64 [B,6] explicit PCG64 states (overrides seeds)
     fixed_starts / fixed_goals   int16 [B,N,2] or [N,2] for ``deterministic`` on synthetic grids
     lanes_per_env   engine tuning knob (0 = auto)
+    jit_specialize  opt-in: when no prebuilt specialisation matches, compile the step kernels for exactly this
+                    configuration when the engine is created (hiprtc, 2-5 s, cached per process); ``launch_info()``
+                    tells whether it took (``jit``) and why not (``jit_note``)
     force_generic_kernel   engine knob: use the runtime-config step kernel even when a compile-time
                     specialisation (BASELINE.json shapes) matches
     force_sequential_reset   engine knob (tests): in-kernel resets always use the sequential restatement of
@@ -92,6 +95,8 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_NO_CELL_MAP
     if cfg.get("force_sequential_reset", False):  # engine knob: in-kernel resets through the sequential sampler only
         f |= L.FLAG_SEQUENTIAL_RESET
+    if cfg.get("jit_specialize", False):  # opt-in: compile the step kernels for exactly this configuration (hiprtc)
+        f |= L.FLAG_JIT_SPECIALIZE
     if cfg.get("force_generic_kernel", False):  # engine knob: skip the compile-time specialised step kernel
         f |= L.FLAG_GENERIC_KERNEL
     return f
@@ -220,8 +225,10 @@ class VecReferenceModel:
     def launch_info(self) -> dict:
         b, t, l, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         special = self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
+        why = C.c_char_p()
+        jit = self._lib.mapf_jit_status(self._h, C.byref(why))
         return {"blocks": b.value, "threads": t.value, "lds_bytes": l.value, "lanes_per_env": p.value,
-                "specialized_kernel": int(special)}
+                "specialized_kernel": int(special), "jit": bool(jit), "jit_note": (why.value or b"").decode(errors="replace")}
 
     # ------------------------------------------------------------------------------------------
     def reset(self, env_mask: torch.Tensor | None = None) -> torch.Tensor:

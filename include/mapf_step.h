@@ -64,6 +64,10 @@ extern "C" {
 #define MAPF_FLAG_LOCK_METRICS 32u        /* enable_lock_metrics [on] */
 #define MAPF_FLAG_DETERMINISTIC 64u       /* deterministic [off]: reset() re-places agents on fixed starts, no RNG */
 #define MAPF_FLAG_SINGLE_AGENT 256u        /* the handle runs the single-agent (CTE) sibling env: use the mapf_cte_* calls */
+#define MAPF_FLAG_JIT_SPECIALIZE 0x10000000u /* opt-in: when no prebuilt specialisation of the step kernels matches, compile
+                                               one for exactly this configuration at mapf_create (hiprtc, a few seconds;
+                                               cached per process).  Falls back to the runtime-config kernels -- with the
+                                               reason in mapf_jit_status() -- when hiprtc or the kernel source is not there */
 #define MAPF_FLAG_SEQUENTIAL_RESET 0x20000000u /* engine knob (tests): in-kernel resets always take the sequential
                                                  * sampler (otherwise only after a Lemire rejection or when F = 2N) */
 #define MAPF_FLAG_NO_CELL_MAP 0x40000000u   /* engine knob (tests / A-B): never use the LDS cell-map path of wide groups */
@@ -268,6 +272,10 @@ int mapf_debug_stamps(mapf_handle h, uint64_t *out /* host */, int32_t max_words
  * background draw [B][4N+4] and the visible stream states [B][6] as they are on the device (host outputs, any may be
  * NULL).  Synchronizes the device. */
 int mapf_debug_slots(mapf_handle h, uint32_t *slots /* host */, uint32_t *stage /* host */, uint64_t *vis /* host */);
+
+/* 1 = this handle steps with a kernel compiled for its configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), 0 = not;
+ * *why (may be NULL) gets a static or handle-owned string: the reason when 0, the compile time when 1. */
+int mapf_jit_status(mapf_handle h, const char **why);
 
 /* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes).
  * Returns >= 0: the id of the compile-time specialisation of the step kernel in use (0 = runtime-config kernel). */

@@ -2,6 +2,7 @@
 """One-off soak (not part of the test suite): the randomized engine-vs-oracle fuzz of
 tests/test_engine_parity_gpu.py with another master seed and many more cases.
 Usage: python tools/soak_fuzz.py [master_seed] [cases] [fused]
+SOAK_JIT=1 in the environment: every engine is created with jit_specialize (kernels compiled for the case's configuration).
 With `fused`, every case also runs mapf_step_many (observations every step) on a fresh engine and compares it, step
 for step and in its final state, with the single-step engine."""
 import os, sys, time
@@ -59,6 +60,8 @@ for case in range(cases):
         extra["force_sequential_reset"] = True
     if rng.random() < 0.2:
         extra["force_generic_kernel"] = True
+    if os.environ.get("SOAK_JIT"):  # every case through step kernels compiled for its configuration (2-5 s per case)
+        extra["jit_specialize"] = True
     p = rng.dirichlet(np.ones(5))
     acts = rng.choice(5, size=(90, B, N), p=p).astype(np.int8)
     try:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""us per step of one configuration, specialised vs runtime-config kernel (graph of 100 launches, staggered episodes).
+"""us per step of one configuration, specialised (prebuilt, or compiled at creation: jit_specialize) vs runtime-config kernel (graph of 100 launches, staggered episodes).
 Usage: python tools/time_config.py <num_envs> <H> <W> <num_agents> <sensor_range> <mask 0|1> [steps_per_episode]"""
 import sys, time, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ SPE = int(sys.argv[7]) if len(sys.argv) > 7 else 100
 grids = synth_grids(B, H, W, 0.2, N, base_seed=5)
 for generic in (False, True, False):
     cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": SR, "steps_per_episode": SPE, "include_action_mask_in_obs": bool(MASK),
-           "grid": np.asarray(grids, dtype=np.uint8), "num_envs": B, "seeds": list(range(B)), "force_generic_kernel": generic}
+           "grid": np.asarray(grids, dtype=np.uint8), "num_envs": B, "seeds": list(range(B)), "force_generic_kernel": generic,
+           "jit_specialize": not generic}  # (only takes when no prebuilt specialisation matches)
     env = VecReferenceModel(cfg); env.reset()
     c = env.get_state()["counters"]; c[:, 0] = np.arange(B) % SPE; env.set_state(counters=c)
     acts = torch.randint(0, 5, (100, B, N), dtype=torch.int8, device=env.device)
@@ -25,5 +26,6 @@ for generic in (False, True, False):
     for _ in range(10): g.replay()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 1000
     env.poll_error()
-    print(f"{'runtime-config' if generic else 'specialised   '} kernel id {env.launch_info()['specialized_kernel']}: {dt * 1e6:.2f} us per step, "
+    li = env.launch_info()
+    print(f"{'runtime-config' if generic else ('compiled now  ' if li['jit'] else 'specialised   ')} kernel id {li['specialized_kernel']}: {dt * 1e6:.2f} us per step, "
           f"{B * N / dt / 1e9:.2f} G agent-steps/s  (L = {env.obs_len})", flush=True)
