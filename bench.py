@@ -244,6 +244,8 @@ def worker(args) -> int:
     b_per = len(env_ids)
     cfg = wl.workload_config(name, env_ids)
     cfg["device"] = str(device)
+    if os.environ.get("MAPF_JIT_PREBUILT_TOO"):  # development A/B: step kernels compiled from the source tree's mapf_kernels.inl
+        cfg["jit_specialize"] = True
     if os.environ.get("MAPF_SEPARATE_OUTPUTS"):  # A/B knob of VecReferenceModel (output tensors in separate allocations)
         cfg["separate_output_tensors"] = True
     env = VecReferenceModel(cfg)

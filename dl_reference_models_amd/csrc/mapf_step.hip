@@ -293,7 +293,9 @@ void jit_specialize(mapf_engine *e) {
     const int N = c.num_agents, lpe = e->lpe;
     if (e->cte) { e->jit_note = "single-agent env: runtime-config kernels only"; return; }
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) { e->jit_note = "MAPF_FLAG_GENERIC_KERNEL is set"; return; }
-    if (e->special) { e->jit_note = "a prebuilt specialisation matches"; return; }
+    // (MAPF_JIT_PREBUILT_TOO: development knob -- compile even when a prebuilt specialisation matches, so that an edited
+    //  mapf_kernels.inl can be timed against the library's own kernels without rebuilding the library)
+    if (e->special && !getenv("MAPF_JIT_PREBUILT_TOO")) { e->jit_note = "a prebuilt specialisation matches"; return; }
     if (lpe != pick_lpe(N)) { e->jit_note = "lanes_per_env overrides the group width"; return; }
     if (N > 16 && !e->use_map) { e->jit_note = "wide group without the LDS cell map"; return; }
     const Hiprtc &rt = hiprtc_api();
