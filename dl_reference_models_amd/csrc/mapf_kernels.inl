@@ -218,6 +218,15 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + (k)] = _t; \
     } while (0)
+// the aux wave of k_step3 (lane 128 of a three-wave workgroup), slots 21, 22, 29..31
+#define MAPF_STAMP_W2(k)                                                                \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        unsigned long long _t;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (p.dbg && threadIdx.x == 128) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + (k)] = _t; \
+    } while (0)
 // sampler waves (wave 0 of a sampler workgroup): slots 0 entry, 1 need known, 2 draw done, 3 placement stored, 4 = active
 #define MAPF_STAMP_SW(k)                                                                \
     do {                                                                                \
@@ -231,6 +240,7 @@ __device__ __forceinline__ void warm_scalar_cache(const Params *__restrict__ pp,
 #define MAPF_STAMP_SW(k) do { } while (0)
 #define MAPF_STAMP(k) do { } while (0)
 #define MAPF_STAMP_W1(k) do { } while (0)
+#define MAPF_STAMP_W2(k) do { } while (0)
 #define MAPF_STAMP_ENTRY() do { } while (0)
 #define MAPF_STAMP_ENTRY_STORE() do { } while (0)
 #endif
@@ -2934,6 +2944,549 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
     MAPF_STAMP_ENTRY_STORE();
 }
 
+// ================================================================================================
+// Three-wave step kernel (round 3): the specialised finite shapes with full small groups (K::kSlicedDraw: N = lanes
+// per env = 4 or 8), launches of at most three waves per SIMD.
+//
+// In k_step the state wave's chain is  loads -> B0 (rows from the observation wave) -> target cell -> move table
+// through LDS -> B1 -> goal logic -> rewards -> records -> lock detector -> info -> stores, and the observation wave
+// idles until B1 (stamps: profiles/r02/stamps_v22*.txt; B1 5.5 k cycles after wave entry, both waves end ~5 k cycles
+// later).  Here the work after the moves is dealt to three waves that all start from their own loads:
+//   wave 0 (state)  own copy of the obstacle rows (no B0), move table exchanged by DPP inside the lane group (no LDS
+//                   round trip), publishes the moves (B1), then goal / reward logic, per-agent outputs, record store;
+//   wave 1 (obs)    as in k_step: rows, B1, observation build, stream out;
+//   wave 2 (aux)    loads the records and the env counters itself, takes the moves at B1, owns lock flags + detector
+//                   (MA-env:577-606), info / counter outputs (:627-656), episode statistics, the MAY_FINISH hint, and
+//                   runs the background draw slice (draw_slice) in its tail instead of in the observation wave's window
+//                   before B1, which this layout closes.
+// Workgroups that are not FAST (a ragged last workgroup, an invalid action) run the two-wave code of k_step: wave 2
+// leaves before any barrier (a barrier only counts the waves that are still alive), wave 0 calls step_body.
+// ================================================================================================
+// value of lane (a ^ k) of the lane group, k = 1 .. LPE-1, for groups of 4 or 8 lanes: quad permutes and the
+// half-row mirror (lane i <-> 7 - i = i ^ 7), all full-rate DPP moves
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_get(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int LPE>
+__device__ __forceinline__ void group_xchg(const uint32_t v, uint32_t (&o)[LPE - 1]) {
+    static_assert(LPE == 4 || LPE == 8, "DPP exchange is written for groups of 4 or 8 lanes");
+    o[0] = dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]: lane ^ 1
+    o[1] = dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]: lane ^ 2
+    o[2] = dpp_get<0x1B>(v);  // quad_perm [3,2,1,0]: lane ^ 3
+    if constexpr (LPE == 8) {
+        const uint32_t m = dpp_get<0x141>(v);  // row_half_mirror: lane ^ 7
+        o[6] = m;
+        o[5] = dpp_get<0xB1>(m);  // lane ^ 6
+        o[4] = dpp_get<0x4E>(m);  // lane ^ 5
+        o[3] = dpp_get<0x1B>(m);  // lane ^ 4
+    }
+}
+
+constexpr uint32_t kObsWDone = 256u, kObsWSuccess = 512u, kObsWDoReset = 1024u;  // for the aux wave (k_step3)
+
+// resolve_moves (same rule, same outcome) with the {old, target} pairs exchanged by DPP
+template <int LPE>
+__device__ __forceinline__ uint32_t resolve_moves_dpp(int lane, int a, uint32_t old, uint32_t tgt) {
+    using gm_t = typename GMask<LPE>::type;
+    uint32_t x[LPE - 1];
+    group_xchg<LPE>(old | (tgt << 16), x);
+    gm_t occ_bit = 0, cont = 0;
+    const bool want = tgt != kNoCell;
+#pragma unroll
+    for (int k = 1; k < LPE; k++) {
+        const gm_t bit = (gm_t)1 << (a ^ k);
+        occ_bit |= ((x[k - 1] & 0xFFFFu) == tgt) ? bit : 0;
+        cont |= ((x[k - 1] >> 16) == tgt) ? bit : 0;
+    }
+    const gm_t below = ((gm_t)1 << a) - 1;
+    cont = want ? (cont & below) : 0;
+    const gm_t occ_low = occ_bit & below;
+    const bool occ_high = (occ_bit & ~below) != 0;
+    const gm_t dep = cont | occ_low;
+    bool resolved = !want, moved = false;
+    gm_t R = gballot_n<LPE>(resolved, lane), M = 0;
+#pragma unroll 1
+    for (int it = 0; it <= LPE; it++) {
+        if (__all(resolved)) break;
+        if (!resolved && (dep & ~R) == 0) {
+            moved = !(occ_high || (occ_low & ~M) != 0 || (cont & M) != 0);
+            resolved = true;
+        }
+        R = gballot_n<LPE>(resolved, lane);
+        M = gballot_n<LPE>(moved, lane);
+    }
+    return moved ? tgt : old;
+}
+
+// what an agent's step means for its own flags, shared by the state wave and the aux wave of k_step3 (finite mode,
+// every lane an agent, no invalid action): MA-env:538-563 goal logic, :581-594 lock flags
+struct AgentStep {
+    bool moved, reached, completed, grs, cur_on_goal, progress, failed;
+    int dist;
+    uint32_t intended1;  // intended_next in the (+1,+1) encoding
+};
+__device__ __forceinline__ AgentStep agent_step(const Lane &st, int act, uint32_t cur) {
+    AgentStep s;
+    const uint32_t old = st.pos;
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
+    s.intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
+    s.moved = cur != old;
+    s.reached = (st.flags & kFlagReached) != 0;
+    s.completed = (st.flags & kFlagCompleted) != 0;
+    s.grs = false;
+    const bool on_goal = cur == st.goal;
+    if (on_goal && !s.reached) {
+        s.reached = true;
+        s.completed = true;
+        s.grs = true;
+    }
+    s.cur_on_goal = on_goal;
+    s.progress = old != st.goal && on_goal;  // !prev_on_goal && cur_on_goal
+    s.failed = act != 0 && !s.moved;
+    s.dist = cell_l1(cur, st.goal);
+    return s;
+}
+
+// ---- wave 2 of k_step3 -------------------------------------------------------------------------------------------
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const Lds &l, unsigned char *aux_lds, const int lane,
+                                          const int env0, const int act, Lane &st, int *sc) {
+    constexpr int G = 64 / LPE;
+    using gm_t = typename GMask<LPE>::type;
+    const int grp = lane / LPE, a = lane % LPE;
+    const int env = env0 + grp;
+    const int N = K::N(p);
+    const uint32_t flags = K::flags(p);
+    const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
+    const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
+    const bool dist_in_rec = lw <= 16;
+
+    MAPF_STAMP_W2(21);
+    wg_sync();  // B1: the moves are published
+    MAPF_STAMP_W2(22);
+    const uint4 ent = l.otab[lane];
+    const uint32_t w = ent.w, cur = ent.y >> 16;  // (word x is the observation wave's: a substituted entry carries the
+                                                 //  reset position there)
+    const bool done = (w & kObsWDone) != 0, do_reset = (w & kObsWDoReset) != 0;
+
+    sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
+    const AgentStep as = agent_step(st, act, cur);
+    const int goals_step = __popcll(gballot<LPE>(as.grs, lane));
+    sc[MAPF_CTR_GOALS_REACHED_TOTAL] += goals_step;
+
+    int delta = 0;
+    bool dl_ok = false, ll_ok = false;
+    if (lock_on) {  // _append_lock_history_step MA-env:374-387 (same arithmetic as step_body)
+        const int t = sc[MAPF_CTR_HIST_ROWS];
+        const int count = min(t + 1, K::hs(p));
+        dl_ok = count >= dw;
+        ll_ok = count >= lw;
+        st.moved = (st.moved << 1) | (as.moved ? 1ull : 0ull);
+        st.failed = (st.failed << 1) | (as.failed ? 1ull : 0ull);
+        st.progress = (st.progress << 1) | (as.progress ? 1ull : 0ull);
+        int d_old = as.dist;
+        if (dist_in_rec) {
+            st.dist.w = (st.dist.w << 8) | (st.dist.z >> 24);
+            st.dist.z = (st.dist.z << 8) | (st.dist.y >> 24);
+            st.dist.y = (st.dist.y << 8) | (st.dist.x >> 24);
+            st.dist.x = (st.dist.x << 8) | (uint32_t)as.dist;
+            const int ob = lw - 1, od = ob >> 2;
+            const uint32_t wd = od == 0 ? st.dist.x : (od == 1 ? st.dist.y : (od == 2 ? st.dist.z : st.dist.w));
+            if (ll_ok) d_old = (int)((wd >> ((ob & 3) * 8)) & 0xFFu);
+        } else {
+            int16_t *ring = io.dist_ring + ((size_t)env * N + a) * ring_stride;
+            const int slot_new = t % lw;
+            const int slot_old = (slot_new + 1 == lw) ? 0 : slot_new + 1;
+            if (ll_ok) d_old = ring[slot_old];
+            ring[slot_new] = (int16_t)as.dist;
+        }
+        delta = d_old - as.dist;
+        sc[MAPF_CTR_HIST_ROWS] = t + 1;
+    }
+    sc[MAPF_CTR_MAY_FINISH] = (gballot<LPE>(as.dist > 1, lane) == 0 ||
+                               sc[MAPF_CTR_STEP_COUNT] + 1 >= io.steps_per_episode) ? 1 : 0;
+
+    // pair pass (MA-env:389-398 neighbour sets, :608-623 intent blocking) on DPP-exchanged entries
+    uint32_t xn[LPE - 1], xy[LPE - 1], xz[LPE - 1];
+    group_xchg<LPE>(cur, xn);
+    group_xchg<LPE>((as.reached ? 1u : 0u) | ((uint32_t)(delta + 256) << 1), xy);
+    group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
+    const uint32_t mycell1 = cur + 0x0101u;
+    gm_t nbr = 0;
+    int sum_biased = 0;
+    bool blocks = false;
+#pragma unroll
+    for (int k = 1; k < LPE; k++) {
+        const int d = cell_l1(xn[k - 1], cur);
+        const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);
+        nbr |= isn ? ((gm_t)1 << (a ^ k)) : 0;
+        sum_biased += isn ? (int)(xy[k - 1] >> 1) : 0;
+        blocks |= xz[k - 1] == mycell1;
+    }
+    const int sum_delta = delta + sum_biased - 256 * __popc((uint32_t)nbr);
+    const bool blocking = as.reached && !as.moved && blocks;
+
+    int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
+    if (lock_on) {  // MA-env:400-438, as step_body
+        const uint64_t mdw = dw >= 64 ? ~0ull : ((1ull << dw) - 1ull);
+        const uint64_t mlw = lw >= 64 ? ~0ull : ((1ull << lw) - 1ull);
+        const gm_t members = nbr | ((gm_t)1 << a);
+        const bool focal = !as.cur_on_goal && __popc((uint32_t)nbr) >= K::min_nbrs(p);
+        const gm_t prog_dw_nz = gballot_n<LPE>((st.progress & mdw) != 0, lane);
+        const gm_t moved_dw_nz = gballot_n<LPE>((st.moved & mdw) != 0, lane);
+        const gm_t fail_dw_nz = gballot_n<LPE>((st.failed & mdw) != 0, lane);
+        const gm_t prog_lw_nz = gballot_n<LPE>((st.progress & mlw) != 0, lane);
+        const gm_t moved_lw_nz = gballot_n<LPE>((st.moved & mlw) != 0, lane);
+        const bool dead_me = focal && dl_ok && (members & (prog_dw_nz | moved_dw_nz)) == 0 && (members & fail_dw_nz) != 0;
+        const bool live_me = focal && ll_ok && (members & prog_lw_nz) == 0 && (members & moved_lw_nz) != 0 &&
+                             sum_delta <= io.eps_floor;
+        deadlock = gballot_n<LPE>(dead_me, lane) != 0;
+        livelock = !deadlock && gballot_n<LPE>(live_me, lane) != 0;
+        const int prev = sc[MAPF_CTR_LOCK_STATE_PREV];
+        dl_event = deadlock && !(prev & 1);
+        ll_event = livelock && !(prev & 2);
+        sc[MAPF_CTR_LOCK_STATE_PREV] = deadlock | (livelock << 1);
+        sc[MAPF_CTR_DEADLOCK_STEPS] += deadlock;
+        sc[MAPF_CTR_LIVELOCK_STEPS] += livelock;
+        sc[MAPF_CTR_DEADLOCK_EVENTS] += dl_event;
+        sc[MAPF_CTR_LIVELOCK_EVENTS] += ll_event;
+    }
+    const int blocking_step = __popcll(gballot<LPE>(blocking, lane));
+    sc[MAPF_CTR_BLOCKING_COUNT] += blocking_step;
+    MAPF_STAMP_W2(29);
+
+    // info (MA-env:627-656) and counters, one coalesced store each (as step_body's FAST branch)
+    const int reached_cnt = __popcll(gballot<LPE>(as.reached, lane));
+    const int completed_cnt = __popcll(gballot<LPE>(as.completed, lane));
+    {
+        const int goals_total = reached_cnt;
+        const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
+        float2 *xi = reinterpret_cast<float2 *>(aux_lds);
+        uint4 *xs = reinterpret_cast<uint4 *>(aux_lds + 512);
+        if (a == 0) {
+            float2 *q = xi + grp * 7;
+            q[0] = make_float2((float)goals_step, (float)goals_total);
+            q[1] = make_float2((float)blocking_step, (float)sc[MAPF_CTR_BLOCKING_COUNT]);
+            q[2] = make_float2((float)deadlock, (float)livelock);
+            q[3] = make_float2((float)dl_event, (float)ll_event);
+            q[4] = make_float2((float)sc[MAPF_CTR_DEADLOCK_EVENTS], (float)sc[MAPF_CTR_LIVELOCK_EVENTS]);
+            q[5] = make_float2((float)sc[MAPF_CTR_DEADLOCK_STEPS], (float)sc[MAPF_CTR_LIVELOCK_STEPS]);
+            q[6] = make_float2((float)completed_cnt / (float)N, (float)goals_total / (float)steps);
+            if (do_reset) {  // a re-placed env stores the counters reset() leaves (MA-env:440-455)
+                xs[grp * 3] = xs[grp * 3 + 1] = make_uint4(0, 0, 0, 0);
+                xs[grp * 3 + 2] = make_uint4(0, sc[MAPF_CTR_EPISODES_DONE] + 1, 1, sc[11]);
+            } else {
+                xs[grp * 3] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+                xs[grp * 3 + 1] = make_uint4(sc[4], sc[5], sc[6], sc[7]);
+                xs[grp * 3 + 2] = make_uint4(sc[8], sc[9], sc[10], sc[11]);
+            }
+        }
+        wave_lds_sync();
+        if (io.info_all) {
+            float2 *dst = reinterpret_cast<float2 *>(io.info_all + (size_t)env0 * MAPF_INFO_ALL);
+            for (int k = lane; k < G * 7; k += 64) dst[k] = xi[k];
+        }
+        if (lane < 3 * G) {
+            const int g = lane / 3, j = lane - 3 * g;
+            store_state16(io.scal + (size_t)(env0 + g) * kScalInts + j * 4, xs[lane]);
+        }
+    }
+    MAPF_STAMP_W2(30);
+    // episode statistics (callbacks.py:236-345), as step_body
+    if (__builtin_expect(__any(done), 0)) {
+        if (done && a == 0) {
+            int *acc = p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC;
+            atomicAdd(acc + MAPF_ACC_EPISODES, 1);
+            if (w & kObsWSuccess) atomicAdd(acc + MAPF_ACC_SUCCESSES, 1);
+            atomicAdd(acc + MAPF_ACC_GOALS_REACHED, sc[MAPF_CTR_GOALS_REACHED_TOTAL]);
+            atomicAdd(acc + MAPF_ACC_BLOCKING_COUNT, sc[MAPF_CTR_BLOCKING_COUNT]);
+            atomicAdd(acc + MAPF_ACC_DEADLOCK_COUNT, sc[MAPF_CTR_DEADLOCK_EVENTS]);
+            atomicAdd(acc + MAPF_ACC_LIVELOCK_COUNT, sc[MAPF_CTR_LIVELOCK_EVENTS]);
+            atomicAdd(acc + MAPF_ACC_DEADLOCK_STEPS, sc[MAPF_CTR_DEADLOCK_STEPS]);
+            atomicAdd(acc + MAPF_ACC_LIVELOCK_STEPS, sc[MAPF_CTR_LIVELOCK_STEPS]);
+            atomicAdd(acc + MAPF_ACC_COMPLETED_AGENTS, completed_cnt);
+            atomicAdd(acc + MAPF_ACC_EPISODE_STEPS, sc[MAPF_CTR_STEP_COUNT]);
+        }
+    }
+    if (__any((w & kObsWReset) != 0)) wg_sync();  // B2 (the state wave's slow reset; all waves of the workgroup meet)
+}
+
+// ---- wave 0 of k_step3 (FAST workgroups) -------------------------------------------------------------------------
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
+                                            const int act, Lane &st, const int step_count_in, uint32_t nsg,
+                                            const bool nsg_lazy) {
+    constexpr int G = 64 / LPE;
+    const int grp = lane / LPE, a = lane % LPE;
+    const int env = env0 + grp;
+    const int N = K::N(p), H = io.H, W = io.W;
+    const uint32_t flags = K::flags(p);
+    const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
+    const bool dist_in_rec = K::lw(p) <= 16;
+    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;  // (l.rows: this wave's own copy)
+    const int step_count = step_count_in + 1;
+
+    // ---- move phase (MA-env:502-526), as step_body ----
+    const uint32_t old = st.pos;
+    const int r_old = (int)(old >> 8), c_old = (int)(old & 255u);
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const int tr = r_old + dr, tc = c_old + dc;
+    const uint64_t trow = myrows[tr];
+    const bool col_ok = io.col_pad != 0 || (tc >= 0 && tc < W);
+    const bool want = act != 0 && col_ok && !((trow >> ((tc + io.col_pad) & 63)) & 1ull);
+    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    MAPF_STAMP(16);
+    uint32_t cur = old;
+    if (__any(want)) cur = resolve_moves_dpp<LPE>(lane, a, old, tgt);
+    MAPF_STAMP(2);
+
+    // ---- termination (MA-env:668-690): success check precedes the step-limit check ----
+    const bool on_goal = cur == st.goal;
+    int term = 0, trunc = 0;
+    float term_reward = 0.0f;
+    {
+        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+        if (n_on_goal == N) {
+            term_reward = 1.0f;
+            term = 1;
+        } else if (step_count >= io.steps_per_episode) {
+            if (!on_goal) term_reward = -1.0f;
+            term = 1;
+            trunc = 1;
+        }
+    }
+    const bool done = (term | trunc) != 0;
+    const bool do_reset = done && io.auto_reset;
+    const bool want_any_obs = io.obs || io.final_obs;
+    const bool pressure_prev = (st.flags & kFlagPressure) != 0;
+    int sel = io.obs ? 0 : 2;
+    uint32_t obs_w0 = kObsWAgent | (pressure_prev ? kObsWPressure : 0u) | kObsWFast | (done ? kObsWDone : 0u) |
+                      ((term && !trunc) ? kObsWSuccess : 0u) | (do_reset ? kObsWDoReset : 0u);
+    bool fast_reset = false, slow_reset = false, subst = false;
+    if (__builtin_expect(__any(do_reset), 0)) {
+        if (nsg_lazy) nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
+        const bool slot_ok = gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
+        // (without observations there is no observation wave at the barriers: such launches take the slow reset, which
+        //  needs none when nothing is observed)
+        fast_reset = do_reset && slot_ok;
+        slow_reset = do_reset && !fast_reset;
+        subst = fast_reset && io.final_obs == nullptr;
+        if (do_reset) sel = io.final_obs ? 1 : ((subst && io.obs) ? 0 : 2);
+        if (subst) obs_w0 = (obs_w0 & ~kObsWPressure) | kObsWFinal;
+        obs_w0 |= (slow_reset ? kObsWReset : 0u) | ((fast_reset && !subst) ? kObsWResetFast : 0u);
+    }
+    obs_w0 |= (uint32_t)sel << kObsWSelShift;
+    {
+        // x old | new << 16, y goal (low half: the observation wave masks it) | the real new cell << 16 (aux wave),
+        // z reset placement, w kObsW* flags
+        uint4 e = make_uint4(old | (cur << 16), (st.goal & 0xFFFFu) | (cur << 16), 0u, obs_w0);
+        if (__builtin_expect(__any(fast_reset), 0)) {
+            const uint32_t rs = nsg, rs_pos = rs & 0xFFFFu;
+            if (fast_reset) e.z = rs;
+            if (subst) e = make_uint4(rs_pos | (rs_pos << 16), (rs >> 16) | (cur << 16), rs, obs_w0);
+        }
+        l.otab[lane] = e;
+    }
+    wg_sync();  // B1
+    MAPF_STAMP(19);
+
+    // ---- goal / reward logic, lock flags of the record ----
+    const AgentStep as = agent_step(st, act, cur);
+    float reward = as.grs ? 0.5f : 0.0f;
+    reward += term_reward;
+    if (lock_on) {
+        st.moved = (st.moved << 1) | (as.moved ? 1ull : 0ull);
+        st.failed = (st.failed << 1) | (as.failed ? 1ull : 0ull);
+        st.progress = (st.progress << 1) | (as.progress ? 1ull : 0ull);
+        if (dist_in_rec) {
+            st.dist.w = (st.dist.w << 8) | (st.dist.z >> 24);
+            st.dist.z = (st.dist.z << 8) | (st.dist.y >> 24);
+            st.dist.y = (st.dist.y << 8) | (st.dist.x >> 24);
+            st.dist.x = (st.dist.x << 8) | (uint32_t)as.dist;
+        }
+    }
+    // intent blocking (MA-env:608-623): some not-yet-reached agent intended to enter my cell
+    uint32_t xz[LPE - 1];
+    group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
+    const uint32_t mycell1 = cur + 0x0101u;
+    bool blocks = false;
+#pragma unroll
+    for (int k = 1; k < LPE; k++) blocks |= xz[k - 1] == mycell1;
+    const bool blocking = as.reached && !as.moved && blocks;
+    MAPF_STAMP(3);
+
+    if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
+    if (io.info_agent) {
+        uchar2 ia;
+        ia.x = blocking ? 1 : 0;
+        ia.y = as.grs ? 1 : 0;
+        reinterpret_cast<uchar2 *>(io.info_agent)[(size_t)env * N + a] = ia;
+    }
+    if (a == 0) {
+        if (io.terminated) io.terminated[env] = (uint8_t)term;
+        if (io.truncated) io.truncated[env] = (uint8_t)trunc;
+    }
+    MAPF_STAMP(17);
+    st.pos = cur;
+    st.flags = (as.reached ? kFlagReached : 0) | (as.completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+    AgentRec *rec0 = io.agents + (size_t)env0 * N;
+    if (!__builtin_expect(__any(slow_reset), 0)) {
+        Lane img = st;
+        if (__builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+            if (fast_reset) {
+                img.start = nsg & 0xFFFFu;
+                img.goal = nsg >> 16;
+                img.pos = img.start;
+                img.flags = 0u;
+                img.moved = img.failed = img.progress = 0ull;
+                img.dist = make_uint4(0, 0, 0, 0);
+                slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;  // consumed
+            }
+        }
+        store_lanes_coalesced(rec0, l.xpose, lane, img);
+        MAPF_STAMP(18);
+        return;
+    }
+    // ---- an env of the wave ends its episode without a pre-drawn placement: draw inline (reset_groups), B2 inside ----
+    {
+        if (fast_reset) {  // the other re-placed groups of the wave
+            st.start = nsg & 0xFFFFu;
+            st.goal = nsg >> 16;
+            st.pos = st.start;
+            st.flags = 0u;
+            st.moved = st.failed = st.progress = 0ull;
+            st.dist = make_uint4(0, 0, 0, 0);
+            slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;
+            nsg = kSlotInvalid;
+        }
+        int sc_unused[12];  // (the aux wave owns the counters; it stores their reset image)
+#pragma unroll
+        for (int k = 0; k < 12; k++) sc_unused[k] = 0;
+        wave_lds_sync();
+        (void)want_any_obs;
+        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, true, true, slow_reset, st,
+                                 sc_unused, io.obs != nullptr, nsg, true);  // B2: the aux wave is always there
+        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, G, slow_reset ? 0 : 2);
+        store_lanes_coalesced(rec0, l.xpose, lane, st);
+    }
+}
+
+template <class K, int LPE, int MW, int WPS = 0>
+__global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+                                                                const IoTail tail) {
+    static_assert(K::kSlicedDraw, "k_step3 is for the specialised finite shapes with full groups of 4 or 8 lanes");
+    MAPF_STAMP_ENTRY();
+    const Params &p = *pp;
+    const Io io = MAPF_IO_JOIN;
+    constexpr int G = 64 / LPE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
+    const int env0 = (int)blockIdx.x * G;
+    const int ngroups = min(G, io.B - env0);
+    const int N = K::N(p);  // == LPE
+    const bool full = ngroups == G;  // wave-uniform
+    const bool env_ok = grp < ngroups;
+    const int env = env_ok ? env0 + grp : io.B - 1;
+    __builtin_amdgcn_s_setprio(2);
+
+    if (wv == 1) {
+        // ---- observation wave: as in k_step, minus B0 and minus the draw slices ----
+        RowRegs rr;
+        rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+        __builtin_amdgcn_sched_barrier(0);
+        warm_scalar_cache(pp, tail);
+        const Lds l = carve_lds(io, lds_raw);
+        rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
+        wave_lds_sync();
+        MAPF_STAMP_W1(10);
+        if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+        return;
+    }
+
+    // ---- waves 0 and 2: agent record, action (both decide FAST from it), and what each of them owns ----
+    RowRegs rr;
+    LaneRaw raw;
+    lane_issue(io.agents + (size_t)env * N + a, raw);
+    int act = (int)io.actions[(size_t)env * N + a];
+    if (wv == 0) rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);  // the state wave's own copy of the rows
+    int sc[12];
+    uint32_t nsg = kSlotInvalid;
+    DrawReq dreq;
+    constexpr bool kSpec = WPS == 0;
+    if (wv == 0) {
+        sc[0] = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
+        if (kSpec) nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
+    } else {
+        load_scal(io.scal, env, sc);
+        draw_request_head<K, LPE, kSpec>(io, N, a, env, dreq);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    warm_scalar_cache(pp, tail);
+    __builtin_amdgcn_sched_barrier(0);
+    Lds l = carve_lds(io, lds_raw);
+#ifdef MAPF_STAMPS
+    if (wv == 0) {  // (experiment: when do the first 16 bytes of the records and the actions arrive?)
+        asm volatile("" ::"v"(raw.q0.x), "v"(act));
+        MAPF_STAMP(4);
+        asm volatile("" ::"v"(raw.q2.x));
+        MAPF_STAMP(5);
+    }
+#endif
+    unsigned char *extra = lds_raw + io.lds_map_off;  // (k_step3: the state wave's rows, then 1 KiB for the aux wave)
+    const int rows_bytes = ((G * (io.H + 2 * kRowPad) * 8) + 15) & ~15;
+    if (wv == 0) {
+        l.rows = reinterpret_cast<uint64_t *>(extra);
+        rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
+        wave_lds_sync();
+    }
+    const bool is_agent = env_ok;  // (N == LPE)
+    Lane st;
+    lane_unpack(raw, full || is_agent, st);
+    act = (full || is_agent) ? act : 0;
+    const bool fast3 = full && !__any(act < 0 || act > 4);
+    MAPF_STAMP(0);
+    MAPF_STAMP(1);
+    if (__builtin_expect(!fast3, 0)) {
+        // ---- a ragged last workgroup or an invalid action: the two-wave code of k_step ----
+        if (wv == 2) return;  // before any barrier
+        load_scal(io.scal, env, sc);
+        nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
+        step_body<K, LPE, MW, false, true>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, false);
+        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (env_ok && a == 0) store_scal(io.scal, env, sc);
+        return;
+    }
+    if (wv == 0) {
+        state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, st, sc[0], nsg, !kSpec);
+        MAPF_STAMP(8);
+#ifdef MAPF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MAPF_STAMP(9);
+        MAPF_STAMP_ENTRY_STORE();
+        return;
+    }
+    // ---- aux wave ----
+    dreq.hint = sc[MAPF_CTR_MAY_FINISH];
+    const int d_stage = draw_request_body<K, LPE, kSpec>(p, io, N, a, env, true, dreq);
+    aux3_wave<K, LPE, MW>(p, io, l, extra + rows_bytes, lane, env0, act, st, sc);
+    if (__builtin_expect(__any(d_stage != 0), 0)) draw_slice<K, LPE>(p, io, l.scratch, lane, env, d_stage, dreq);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        int run = 0;
+        for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
+        if (p.dbg && threadIdx.x == 128) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
+    }
+#endif
+    MAPF_STAMP_W2(31);
+}
+
 // ------------------------------------------------------------------------------------------------
 // T steps in one launch (mapf_step_many): state stays in registers, obstacle rows stay in LDS, only the
 // per-step action bytes are read and the per-step outputs written.  actions [T][B][N]; every non-null
@@ -3424,6 +3977,9 @@ constexpr uint32_t kFlagsHeadline = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_A
                                     MAPF_FLAG_BLOCKING_PRESSURE | MAPF_FLAG_LOCK_METRICS;  // L = 33
 constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_BLOCKING_PRESSURE |
                                       MAPF_FLAG_LOCK_METRICS;  // the reference's default obs, L = 28
+#ifdef MAPF_DEV_C3  // development builds (mapf_step.hip): the headline shape only
+#define MAPF_SPECIALIZATIONS(X) X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)
+#else
 #define MAPF_SPECIALIZATIONS(X)                                            \
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)                              \
     X(2, 4, 2, kFlagsHeadline, 8, 16, 2, 1, 4)                              \
@@ -3431,5 +3987,6 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
     X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8)                            \
     X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)                            \
     X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)  /* the reference's own training setup, main.py:55-67: 16 agents, 7x7 */
+#endif
 
 }  // namespace

@@ -46,6 +46,20 @@
 
 #include "mapf_kernels.inl"
 
+// Group widths and window-mask widths the dispatchers below instantiate.  -DMAPF_DEV_C3 (development builds only: the
+// library is then good for the c3 shape and nothing else) cuts them to what the headline shape needs, so that an edit of
+// the step kernel can be compiled in under a minute instead of several.
+#ifdef MAPF_DEV_C3
+#define MAPF_FOR_LPE(X) X(8)
+#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
+#else
+#define MAPF_FOR_LPE(X) X(4) X(8) X(16) X(32) X(64)
+#define MAPF_MW_DISPATCH(e, F, L, ...)                     \
+    if ((e)->mask_w == 32) return F<L, 32>(__VA_ARGS__);   \
+    if ((e)->mask_w == 64) return F<L, 64>(__VA_ARGS__);   \
+    return F<L, 128>(__VA_ARGS__);
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -62,6 +76,7 @@ struct mapf_engine {
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
+    int three_wave = 0;  // k_step3 (state / observation / aux wave): specialised finite shapes with N = 4 or 8, not dense
     // step kernels compiled for exactly this configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), else null
     hipFunction_t jit_step = nullptr, jit_many = nullptr;
     std::string jit_note = "not requested (MAPF_FLAG_JIT_SPECIALIZE)";
@@ -193,6 +208,10 @@ constexpr int mask_width_for(int sr) {
 // small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
 template <class K, int LPE, int MW>
 hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
+    if constexpr (K::kSlicedDraw) {
+        if (e->three_wave)
+            LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks), dim3(192), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
+    }
     if constexpr (LPE < 32) {
         if (e->dense)
             LAUNCH_CHECKED((k_step<K, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
@@ -400,18 +419,10 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
-#define MAPF_CASE(L)                                                               \
-    case L:                                                                        \
-        if (e->mask_w == 32) return launch_many_t<L, 32>(e, io, T, obs_mode, pol, s);   \
-        if (e->mask_w == 64) return launch_many_t<L, 64>(e, io, T, obs_mode, pol, s);   \
-        return launch_many_t<L, 128>(e, io, T, obs_mode, pol, s);
-    switch (e->lpe) {
-        MAPF_CASE(4)
-        MAPF_CASE(8)
-        MAPF_CASE(16)
-        MAPF_CASE(32)
-        MAPF_CASE(64)
-    }
+#define MAPF_CASE(L) \
+    case L:          \
+        MAPF_MW_DISPATCH(e, launch_many_t, L, e, io, T, obs_mode, pol, s)
+    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
     return hipErrorInvalidValue;
 }
@@ -419,18 +430,10 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
 hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP && e->jit_step) return launch_jit_step(e, io, s);
     if (kind == KIND_STEP && e->special) return launch_specialized_step(e, io, s);
-#define MAPF_CASE(L)                                                       \
-    case L:                                                                \
-        if (e->mask_w == 32) return launch_kind<L, 32>(kind, e, io, s);    \
-        if (e->mask_w == 64) return launch_kind<L, 64>(kind, e, io, s);    \
-        return launch_kind<L, 128>(kind, e, io, s);
-    switch (e->lpe) {
-        MAPF_CASE(4)
-        MAPF_CASE(8)
-        MAPF_CASE(16)
-        MAPF_CASE(32)
-        MAPF_CASE(64)
-    }
+#define MAPF_CASE(L) \
+    case L:          \
+        MAPF_MW_DISPATCH(e, launch_kind, L, kind, e, io, s)
+    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
     return hipErrorInvalidValue;
 }
@@ -588,6 +591,21 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         }
         // the wide specialisations are compiled for the cell-map path only (KFixed::kMapAlways)
         if (e->special && N > 16 && !e->use_map) e->special = 0;
+    }
+    // k_step3: the specialised finite shapes with full groups of 4 or 8 lanes, while a launch has at most three waves per
+    // SIMD (three waves per workgroup: beyond that the two-wave kernel's 128-register build is the one that fits)
+    if (e->special && !e->sampler_blocks && !cte && (N == 4 || N == 8) && lpe == N &&
+        !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC))) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
+        e->three_wave = (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus;
+        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->three_wave = e->three_wave && atoi(f) == 0;
+        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = atoi(f) != 0;  // test / A-B knob
+        if (e->three_wave) {
+            e->dense = 0;
+            e->lds_map_off = e->lds_bytes;  // (no cell map at these widths) the state wave's rows, 1 KiB for the aux wave
+            e->lds_bytes += rows_bytes + 1024;
+        }
     }
     if (e->sampler_blocks) {  // the sampler workgroups of a k_step launch have their own LDS layout
         const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
@@ -1070,13 +1088,7 @@ static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, h
     case L:                                                                                                          \
         if (step) LAUNCH_CHECKED((k_cte_step<L>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io);      \
         LAUNCH_CHECKED((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
-    switch (e->lpe) {
-        MAPF_CASE(4)
-        MAPF_CASE(8)
-        MAPF_CASE(16)
-        MAPF_CASE(32)
-        MAPF_CASE(64)
-    }
+    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
     return hipErrorInvalidValue;
 }
@@ -1215,7 +1227,7 @@ int mapf_debug_slots(mapf_handle e, uint32_t *slots, uint32_t *stage, uint64_t *
 int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env) {
     if (!e) return MAPF_ERR_CONFIG;
     if (blocks) *blocks = e->blocks;
-    if (threads) *threads = step_threads(e->lpe);  /* step kernels: state wave + observation wave */
+    if (threads) *threads = e->three_wave ? 192 : step_threads(e->lpe);  /* step kernels: state wave + observation wave (+ aux wave) */
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (lanes_per_env) *lanes_per_env = e->lpe;
     return e->special;  /* >= 0: id of the compile-time specialisation in use (0 = runtime-config kernel) */

@@ -30,6 +30,8 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
             H, W = int(rng.integers(3, 65)), int(rng.integers(3, 65))
         cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2,
                "steps_per_episode": int(rng.choice([1, 2, 3, 5, 9, 17, 40, 100])), "include_action_mask_in_obs": bool(rng.integers(0, 2))}
+        if os.environ.get("SOAK_MASK"):  # (development builds that only hold the L = 33 specialisations)
+            cfg["include_action_mask_in_obs"] = True
         if N == 16:  # specialisation 6: the reference's own training setup (main.py:55-67), sampler workgroups in front
             cfg.update(sensor_range=3, include_action_mask_in_obs=False)
         B = int(rng.choice([1, 7, 8, 9, 63, 64, 65, 200, 513]))

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Diagnostic: timeline of the three-wave step kernel (k_step3) from in-kernel s_memtime stamps, in cycles after the
+state wave's entry (median / p95 over workgroups and launches, and for the slowest workgroup of each launch).
+
+Needs a -DMAPF_STAMPS library (never the shipped one): MAPF_STAMPS_LIB=<path> python tools/stamps3.py [--stagger]
+"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["MAPF_LIB"] = os.environ["MAPF_STAMPS_LIB"]
+import torch
+from dl_reference_models_amd import workloads as wl
+from dl_reference_models_amd.vec_env import VecReferenceModel
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+stagger = "--stagger" in sys.argv
+name = args[0] if args else wl.HEADLINE
+b = wl.WORKLOADS[name][0]
+cfg = wl.workload_config(name, list(range(b)))
+env = VecReferenceModel(cfg)
+env.reset()
+if stagger:
+    c = env.get_state()["counters"].copy()
+    c[:, 0] = np.arange(b) % int(cfg["steps_per_episode"])
+    env.set_state(counters=c)
+acts = torch.randint(0, 5, (64, b, cfg["num_agents"]), dtype=torch.int8, device=env.device)
+for t in range(130):
+    env.step(acts[t % 64])
+torch.cuda.synchronize()
+info = env.launch_info()
+blocks, ROW = info["blocks"], 32
+rows = []
+for t in range(20):
+    env.step(acts[t % 64])
+    buf = np.zeros((blocks + 4096) * ROW, dtype=np.uint64)
+    n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+    rows.append(buf[: blocks * ROW].reshape(blocks, ROW).astype(np.int64))
+full = np.stack(rows)
+rel = full - full[:, :, 15:16]
+names = {4: "W0 first 16 B of records + actions", 5: "W0 whole records", 0: "W0 state in registers (stamp 0)", 16: "W0 target cell known", 2: "W0 moves resolved", 19: "W0 past B1", 3: "W0 goal logic + blocking done",
+         17: "W0 rewards / flags issued", 18: "W0 records issued", 8: "W0 body done", 9: "W0 stores drained",
+         10: "W1 rows in LDS", 11: "W1 past B1", 12: "W1 observation staged", 13: "W1 stream issued", 14: "W1 stream drained",
+         21: "W2 state in registers", 22: "W2 past B1", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
+order = [4, 5, 0, 16, 2, 19, 3, 17, 18, 8, 9, 10, 11, 12, 13, 14, 21, 22, 29, 30, 31]
+print(f"workload {name} ({'staggered' if stagger else 'synchronised'}): {blocks} workgroups x {info['threads']} threads; cycles after the state wave's entry")
+end = np.max(np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]]), axis=0)
+slow = end.argmax(axis=1)
+for k in order:
+    v = rel[:, :, k][full[:, :, k] > 0]
+    if v.size == 0:
+        continue
+    sl = np.array([rel[t, slow[t], k] for t in range(rel.shape[0])])
+    print(f"  {names[k]:34s} median {np.median(v):7.0f}  p95 {np.percentile(v, 95):7.0f}   slowest workgroup {np.median(sl):7.0f}")
+print(f"  workgroup end (last of the three)  median {np.median(end):7.0f}  p95 {np.percentile(end, 95):7.0f}   slowest workgroup {np.median(end.max(axis=1)):7.0f}")
+kind = full[:, :, 23]
+if (kind > 0).any():
+    print(f"  aux waves running a draw slice per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
+    for k in range(1, 8):
+        m = kind == k
+        if m.any():
+            dur = (full[:, :, 31] - full[:, :, 30])[m]
+            print(f"    slice {k}: info stored -> end, median {np.median(dur):6.0f}  p95 {np.percentile(dur, 95):6.0f}")
