@@ -29,22 +29,38 @@
 #ifndef MAPF_NS
 #define MAPF_NS
 #endif
+#ifndef MAPF_ABL
+#define MAPF_ABL 0  // development ablations of k_step3 (never in a shipped build)
+#endif
 namespace MAPF_NS {
 
 // ------------------------------------------------------------------------------------------------
 // device-side data layout
 // ------------------------------------------------------------------------------------------------
-// Agent record, 48 B, array [B][N] (env-major; a wave reads 64 consecutive records = 3 KiB).
-//   w0: pos (row<<8 | col) | goal<<16      w1: start | flags<<16
-//   moved / failed / progress: lock-history shift registers, bit k = flag k steps ago
-//   dist[4]: goal-distance history as 16 x uint8, byte k = distance k steps ago (used when the livelock
-//            window is <= 16 steps; longer windows use the separate int16 ring)
-struct AgentRec {
+// Agent state: 48 B per agent as FOUR PLANES over the agent index i = env * N + a (structure of arrays, one allocation,
+// plane k starts agent_plane_off(k, bn8) bytes behind plane 0; env-major, so a wave's 64 agents are one contiguous run
+// in every plane and every load / store of a wave is fully coalesced):
+//   plane 0,  8 B  "hot": w0 = pos (row<<8 | col) | goal << 16,  w1 = start | flags << 16 | pass << 24
+//                  -- all the move phase needs: the state wave of k_step3 waits for these 512 bytes per wave only
+//   plane 1, 16 B  moved, failed          lock-history shift registers, bit k = flag k steps ago
+//   plane 2, 16 B  progress, dist[0..1]   dist[4]: goal-distance history as 16 x uint8, byte k = distance k steps ago
+//   plane 3,  8 B  dist[2..3]             (used when the livelock window is <= 16 steps; longer windows: the int16 ring)
+// pass = which neighbours of `pos` an agent can step on as far as the GRID goes (bit 0 up, 1 right, 2 down, 3 left: no
+// obstacle, inside the grid), a cache derived from pos and the obstacle rows by whoever stores a position
+// (agent_pass_bits); it saves the state wave of k_step3 the obstacle rows altogether.
+// (Rounds 1-2 kept 48-byte records; their stores needed a transpose through LDS to be coalesced, and any wave that
+// wanted the position pulled all 3 KiB of a wave's records through the memory system.)
+struct AgentRec {  // host-side image of one agent (mapf_get_state / mapf_set_state assemble it from the planes)
     uint32_t w0, w1;
     uint64_t moved, failed, progress;
     uint32_t dist[4];
 };
 static_assert(sizeof(AgentRec) == 48, "AgentRec must be 48 bytes");
+__host__ __device__ constexpr uint32_t agent_plane_stride(int B, int N) { return ((uint32_t)B * (uint32_t)N * 8u + 255u) & ~255u; }
+__host__ __device__ constexpr size_t agent_plane_off(int k, uint32_t bn8) {  // plane sizes 1, 2, 2, 1 x bn8
+    return (size_t)bn8 * (k == 0 ? 0 : (k == 1 ? 1 : (k == 2 ? 3 : 5)));
+}
+__host__ __device__ constexpr size_t agent_state_bytes(uint32_t bn8) { return (size_t)bn8 * 6; }
 
 constexpr int kFlagReached = 1, kFlagCompleted = 2, kFlagPressure = 4;
 constexpr int kScalInts = MAPF_NUM_COUNTERS;  // 16 int32 = 64 B per env
@@ -133,12 +149,12 @@ struct Params {
 // state loads then leave in the wave's first cycles instead of behind a scalar-load round trip (build.py,
 // -amdgpu-kernarg-preload-count).
 struct IoHead {
-    AgentRec *agents;
+    uint2 *agents;               // plane 0 of the agent state (the other planes: agent_plane_off)
     int *scal;
     const uint64_t *grid_rows;   // [B][H], bit c = obstacle, bits >= W set
     const int8_t *actions;
     int B, H, W;
-    int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 54), else 0
+    uint32_t bn8;                // agent_plane_stride(B, N)
 };
 struct IoTail {
     int16_t *dist_ring;          // [B][N][ring_stride], slot = history row index mod lw (only when lw > 16)
@@ -161,12 +177,15 @@ struct IoTail {
     const uint16_t *free_cells;
     uint64_t *vis_rng;
 };
-struct Io : IoHead, IoTail {};
+struct Io : IoHead, IoTail {
+    int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 64 - 2 * kRowPad), else 0; a function of W
+};
+__host__ __device__ constexpr int col_pad_for(int W) { return W <= 64 - 2 * kRowPad ? kRowPad : 0; }
 #define MAPF_IO_HEAD_PARAMS                                                                                          \
-    AgentRec *a_agents, int *a_scal, const uint64_t *a_grid_rows, const int8_t *a_actions, const int a_B, const int a_H, \
-        const int a_W, const int a_col_pad
-__device__ __forceinline__ Io join_io(AgentRec *agents, int *scal, const uint64_t *grid_rows, const int8_t *actions, int B,
-                                      int H, int W, int col_pad, const IoTail &tail) {
+    uint2 *a_agents, int *a_scal, const uint64_t *a_grid_rows, const int8_t *a_actions, const int a_B, const int a_H, \
+        const int a_W, const uint32_t a_bn8
+__device__ __forceinline__ Io join_io(uint2 *agents, int *scal, const uint64_t *grid_rows, const int8_t *actions, int B,
+                                      int H, int W, uint32_t bn8, const IoTail &tail) {
     Io io;
     static_cast<IoTail &>(io) = tail;
     io.agents = agents;
@@ -176,10 +195,11 @@ __device__ __forceinline__ Io join_io(AgentRec *agents, int *scal, const uint64_
     io.B = B;
     io.H = H;
     io.W = W;
-    io.col_pad = col_pad;
+    io.bn8 = bn8;
+    io.col_pad = col_pad_for(W);
     return io;
 }
-#define MAPF_IO_JOIN join_io(a_agents, a_scal, a_grid_rows, a_actions, a_B, a_H, a_W, a_col_pad, tail)
+#define MAPF_IO_JOIN join_io(a_agents, a_scal, a_grid_rows, a_actions, a_B, a_H, a_W, a_bn8, tail)
 
 // Scalar-cache warm-up, first statement of the hot kernels.  The compiler fetches kernel arguments and Params
 // fields lazily, one scalar load (and one full wait) per first use, so a wave would pay a chain of scalar-cache
@@ -663,88 +683,76 @@ struct Lane {
     uint4 dist;  // 16 x uint8 goal-distance history
 };
 
-// `rec` must be readable for every lane (callers clamp the index of idle lanes to a real record): the three
-// 16-byte loads are unconditional, so they issue back to back with the wave's other loads instead of sitting in
-// an exec-masked branch with its own wait; idle lanes then replace what they read by the sentinels.
+// Index `idx` must be readable for every lane (callers clamp the index of idle lanes to a real agent): the four loads
+// are unconditional, so they issue back to back with the wave's other loads instead of sitting in an exec-masked
+// branch with its own wait; idle lanes then replace what they read by the sentinels.
 // Two halves so that a kernel can put other work (issuing more loads, waiting for scalar loads) between the
 // issue and the first use.
 struct LaneRaw {
-    uint4 q0, q1, q2;
+    uint2 h;       // plane 0
+    uint4 q1, q2;  // planes 1, 2
+    uint2 d;       // plane 3
 };
-__device__ __forceinline__ void lane_issue(const AgentRec *rec, LaneRaw &r) {
-    const uint4 *rp = reinterpret_cast<const uint4 *>(rec);
-    r.q0 = rp[0];
-    r.q1 = rp[1];
-    r.q2 = rp[2];
+__device__ __forceinline__ const uint4 *agent_plane16(const uint2 *hot, uint32_t bn8, int k) {
+    return reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(hot) + agent_plane_off(k, bn8));
+}
+__device__ __forceinline__ void lane_issue_hist(const uint2 *hot, uint32_t bn8, size_t idx, LaneRaw &r) {
+    r.q1 = agent_plane16(hot, bn8, 1)[idx];
+    r.q2 = agent_plane16(hot, bn8, 2)[idx];
+    r.d = reinterpret_cast<const uint2 *>(agent_plane16(hot, bn8, 3))[idx];
+}
+__device__ __forceinline__ void lane_issue(const uint2 *hot, uint32_t bn8, size_t idx, LaneRaw &r) {
+    r.h = hot[idx];
+    lane_issue_hist(hot, bn8, idx, r);
 }
 __device__ __forceinline__ void lane_unpack(const LaneRaw &r, bool is_agent, Lane &st) {
-    const uint4 q0 = r.q0, q1 = r.q1;
-    st.dist = is_agent ? r.q2 : make_uint4(0, 0, 0, 0);
-    st.pos = is_agent ? (q0.x & 0xFFFFu) : (uint32_t)kIdleCell;
-    st.goal = is_agent ? (q0.x >> 16) : (uint32_t)kIdleGoal;
-    st.start = is_agent ? (q0.y & 0xFFFFu) : (uint32_t)kIdleCell;
-    st.flags = is_agent ? ((q0.y >> 16) & 0xFFu) : 0u;
-    st.moved = is_agent ? ((uint64_t)q0.z | ((uint64_t)q0.w << 32)) : 0ull;
-    st.failed = is_agent ? ((uint64_t)q1.x | ((uint64_t)q1.y << 32)) : 0ull;
-    st.progress = is_agent ? ((uint64_t)q1.z | ((uint64_t)q1.w << 32)) : 0ull;
+    st.dist = is_agent ? make_uint4(r.q2.z, r.q2.w, r.d.x, r.d.y) : make_uint4(0, 0, 0, 0);
+    st.pos = is_agent ? (r.h.x & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.goal = is_agent ? (r.h.x >> 16) : (uint32_t)kIdleGoal;
+    st.start = is_agent ? (r.h.y & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.flags = is_agent ? ((r.h.y >> 16) & 0xFFu) : 0u;
+    st.moved = is_agent ? ((uint64_t)r.q1.x | ((uint64_t)r.q1.y << 32)) : 0ull;
+    st.failed = is_agent ? ((uint64_t)r.q1.z | ((uint64_t)r.q1.w << 32)) : 0ull;
+    st.progress = is_agent ? ((uint64_t)r.q2.x | ((uint64_t)r.q2.y << 32)) : 0ull;
 }
-__device__ __forceinline__ void load_lane(const AgentRec *rec, bool is_agent, Lane &st) {
+__device__ __forceinline__ void load_lane(const uint2 *hot, uint32_t bn8, size_t idx, bool is_agent, Lane &st) {
     LaneRaw r;
-    lane_issue(rec, r);
+    lane_issue(hot, bn8, idx, r);
     lane_unpack(r, is_agent, st);
 }
 
 // 16-byte state store (plain: write-through and nontemporal variants were measured and are slower)
 __device__ __forceinline__ void store_state16(void *dst, const uint4 v) { *reinterpret_cast<uint4 *>(dst) = v; }
 
-__device__ __forceinline__ void store_lane(AgentRec *rec, const Lane &st) {
-    uint4 *rp = reinterpret_cast<uint4 *>(rec);
-    uint4 q0, q1;
-    q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
-    q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
-    q0.z = (uint32_t)st.moved;
-    q0.w = (uint32_t)(st.moved >> 32);
-    q1.x = (uint32_t)st.failed;
-    q1.y = (uint32_t)(st.failed >> 32);
-    q1.z = (uint32_t)st.progress;
-    q1.w = (uint32_t)(st.progress >> 32);
-    store_state16(rp, q0);
-    store_state16(rp + 1, q1);
-    store_state16(rp + 2, st.dist);
+// Which neighbours of `cell` can be stepped on as far as the grid goes (bit 0 up, 1 right, 2 down, 3 left): exactly the
+// test of the move phase (MA-env:508-512: inside the grid and not an obstacle) for the four targets.  myrows = the env's
+// row 0 in LDS (sentinel rows on either side: rows -1 and H read as all obstacles).
+__device__ __forceinline__ uint32_t agent_pass_bits(const uint64_t *myrows, uint32_t cell, int col_pad, int W) {
+    const int r = (int)(cell >> 8), c = (int)(cell & 255u);
+    const uint64_t up = myrows[r - 1], mid = myrows[r], dn = myrows[r + 1];
+    const bool lf_ok = col_pad != 0 || c > 0, rt_ok = col_pad != 0 || c + 1 < W;
+    const uint32_t b_up = (uint32_t)(up >> ((c + col_pad) & 63)) & 1u;
+    const uint32_t b_dn = (uint32_t)(dn >> ((c + col_pad) & 63)) & 1u;
+    const uint32_t b_rt = rt_ok ? ((uint32_t)(mid >> ((c + 1 + col_pad) & 63)) & 1u) : 1u;
+    const uint32_t b_lf = lf_ok ? ((uint32_t)(mid >> ((c - 1 + col_pad) & 63)) & 1u) : 1u;
+    return (b_up | (b_rt << 1) | (b_dn << 2) | (b_lf << 3)) ^ 15u;
 }
 
-// A full wave's 64 records are 3 KiB of contiguous memory, but lane i owns bytes [48i, 48i + 48): stored from the
-// lanes directly, each of the three 16-byte stores touches all 24 cache lines with a third of their bytes.  Going
-// through LDS turns them into three fully coalesced 1 KiB stores (c3: 6.13 -> 5.71 us per step).
-// MAPF_STATE_POLICY = cache policy of those stores (buffer-store aux bits): 0 plain (measured best), 2 nontemporal
-// (5.75 us), 16 sc1 write-through (5.77 us), 18 both (5.98 us).
-#ifndef MAPF_STATE_POLICY
-#define MAPF_STATE_POLICY 0
-#endif
-typedef unsigned int v4u_state_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_lanes_coalesced(AgentRec *rec0, uint4 *xpose, int lane, const Lane &st) {
-    uint4 q0, q1;
-    q0.x = (st.pos & 0xFFFFu) | (st.goal << 16);
-    q0.y = (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16);
-    q0.z = (uint32_t)st.moved;
-    q0.w = (uint32_t)(st.moved >> 32);
-    q1.x = (uint32_t)st.failed;
-    q1.y = (uint32_t)(st.failed >> 32);
-    q1.z = (uint32_t)st.progress;
-    q1.w = (uint32_t)(st.progress >> 32);
-    xpose[3 * lane] = q0;
-    xpose[3 * lane + 1] = q1;
-    xpose[3 * lane + 2] = st.dist;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(rec0, 0, 64 * 48, 0x00020000);
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint4 v = xpose[k * 64 + lane];
-        const v4u_state_t w = {v.x, v.y, v.z, v.w};
-        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (k * 64 + lane) * 16, 0, MAPF_STATE_POLICY);
-    }
+__device__ __forceinline__ void store_lane_hot(uint2 *hot, size_t idx, const Lane &st, uint32_t pass) {
+    hot[idx] = make_uint2((st.pos & 0xFFFFu) | (st.goal << 16), (st.start & 0xFFFFu) | ((st.flags & 0xFFu) << 16) | (pass << 24));
+}
+__device__ __forceinline__ void store_lane_hist(uint2 *hot, uint32_t bn8, size_t idx, const Lane &st) {
+    uint4 *p1 = const_cast<uint4 *>(agent_plane16(hot, bn8, 1)), *p2 = const_cast<uint4 *>(agent_plane16(hot, bn8, 2));
+    uint2 *p3 = reinterpret_cast<uint2 *>(const_cast<uint4 *>(agent_plane16(hot, bn8, 3)));
+    store_state16(p1 + idx, make_uint4((uint32_t)st.moved, (uint32_t)(st.moved >> 32), (uint32_t)st.failed, (uint32_t)(st.failed >> 32)));
+    store_state16(p2 + idx, make_uint4((uint32_t)st.progress, (uint32_t)(st.progress >> 32), st.dist.x, st.dist.y));
+    p3[idx] = make_uint2(st.dist.z, st.dist.w);
+}
+// the whole agent; `myrows` = the env's obstacle rows in LDS (for the pass bits of st.pos)
+__device__ __forceinline__ void store_lane(uint2 *hot, uint32_t bn8, size_t idx, const Lane &st, const uint64_t *myrows,
+                                           int col_pad, int W) {
+    store_lane_hot(hot, idx, st, agent_pass_bits(myrows, st.pos, col_pad, W));
+    store_lane_hist(hot, bn8, idx, st);
 }
 
 __device__ __forceinline__ void load_scal(const int *scal, int env, int *sc) {
@@ -956,17 +964,13 @@ __device__ __forceinline__ float goal_delta(int d, float den, bool normalise) {
 // the flat observation row (MA-env:306-328) from the window masks: cell codes by priority obstacle / out-of-bounds
 // 1 > other agent 2 > own goal 3 > other goal 4 > empty 0, as three bit planes, four cells per round (bit spread +
 // byte->float converts); then goal delta, optional goal distance, pressure flag, action mask (MA-env:749-773)
+// from the three bit planes of the cell codes (code = bit0 | bit1 << 1 | g4 << 2) and the blocked cells oa
 template <class K, int MW, int MAXV>
-__device__ __forceinline__ void emit_obs_row(const Params &p, float *srow, const WMask<MW> &obst, const WMask<MW> &agm,
-                                             const WMask<MW> &goals, const WMask<MW> &own, float gd_r, float gd_c,
-                                             bool pressure) {
+__device__ __forceinline__ void emit_obs_planes(const Params &p, float *srow, const WMask<MW> &bit0, const WMask<MW> &bit1,
+                                                const WMask<MW> &g4, const WMask<MW> &oa, float gd_r, float gd_c,
+                                                bool pressure) {
     const int V = K::V(p), sr = K::sr(p), VV = V * V, ctr = sr * V + sr;
     const uint32_t flags = K::flags(p);
-    const WMask<MW> oa = obst | agm;
-    const WMask<MW> g3 = own.andnot(oa);
-    const WMask<MW> g4 = goals.andnot(oa | own);
-    const WMask<MW> bit0 = obst | g3;
-    const WMask<MW> bit1 = agm.andnot(obst) | g3;
     constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
 #pragma unroll
     for (int t0 = 0; t0 < MAXV * MAXV; t0 += 4) {
@@ -998,6 +1002,17 @@ __device__ __forceinline__ void emit_obs_row(const Params &p, float *srow, const
         q[3] = dn ? 1.0f : 0.0f;
         q[4] = lf ? 1.0f : 0.0f;
     }
+}
+template <class K, int MW, int MAXV>
+__device__ __forceinline__ void emit_obs_row(const Params &p, float *srow, const WMask<MW> &obst, const WMask<MW> &agm,
+                                             const WMask<MW> &goals, const WMask<MW> &own, float gd_r, float gd_c,
+                                             bool pressure) {
+    const WMask<MW> oa = obst | agm;
+    const WMask<MW> g3 = own.andnot(oa);
+    const WMask<MW> g4 = goals.andnot(oa | own);
+    const WMask<MW> bit0 = obst | g3;
+    const WMask<MW> bit1 = agm.andnot(obst) | g3;
+    emit_obs_planes<K, MW, MAXV>(p, srow, bit0, bit1, g4, oa, gd_r, gd_c, pressure);
 }
 
 struct PairOut {
@@ -1749,7 +1764,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
 
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
@@ -1760,7 +1775,8 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
                              io.obs != nullptr, nsg);
     if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     if (do_reset) {
-        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (is_agent)
+            store_lane(io.agents, io.bn8, (size_t)env * N + a, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
         if (a == 0) store_scal(io.scal, env, sc);
     }
 }
@@ -1785,7 +1801,7 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
     const bool is_agent = env_ok && a < N;
     load_rows_to_lds<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
     uint4 *tabg = l.tab + grp * LPE;
     tabg[a] = static_entry(st.pos, st.goal);
     wave_lds_sync();
@@ -1818,13 +1834,13 @@ constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSe
                    kObsWReset = 64u,       // the state wave builds this group's reset observation itself, after B2
                    kObsWResetFast = 128u;  // the observation wave builds it (second pass) from entry word z
 
-// rec0 != nullptr (single-step kernel, full wave): the wave's 64 agent records and the envs' counters are stored
+// store_inside (single-step kernel, full wave): the wave's 64 agents and the envs' counters are stored
 // from inside the body, as soon as they are final, unless an env of the wave resets in this launch; returns
 // whether that happened.
 template <class K, int LPE, int MW, bool FAST, bool DUAL>
 __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
                                           const int ngroups, int act, Lane &st, int *sc, uint32_t &nsg,
-                                          AgentRec *rec0 = nullptr, const bool nsg_lazy = false) {
+                                          const bool store_inside = false, const bool nsg_lazy = false) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const bool env_ok = FAST ? true : (grp < ngroups);
@@ -2213,7 +2229,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     }
     MAPF_STAMP(17);  // (sub-stamp: rewards / per-agent info / done flags issued)
     bool records_stored = false;
-    if (FAST && rec0 != nullptr && !__any(slow_reset)) {
+    if (FAST && store_inside && !__any(slow_reset)) {
         st.pos = cur;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
         Lane img = st;
@@ -2228,7 +2244,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
             img.progress = fast_reset ? 0ull : st.progress;
             img.dist = fast_reset ? make_uint4(0, 0, 0, 0) : st.dist;
         }
-        store_lanes_coalesced(rec0, l.xpose, lane, img);
+        store_lane(io.agents, io.bn8, (size_t)env0 * N + lane, img, myrows, io.col_pad, W);
         records_stored = true;
     }
 
@@ -2400,13 +2416,13 @@ __device__ __forceinline__ Lds with_parity(const Lds &l, int t) {
 // sampling, which only touches the group's scratch, runs before B2).
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                              const int ngroups) {
+                                              const int ngroups, const bool past_b1 = false) {
     const int grp = lane / LPE, a = lane % LPE;
     const int N = K::N(p), H = io.H;
     const uint4 *otabg = l.otab + grp * LPE;
     const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = l.stage + (size_t)(grp * N + min(a, N - 1)) * K::L(p);
-    wg_sync();  // B1
+    if (!past_b1) wg_sync();  // B1
     MAPF_STAMP_W1(11);
     const uint4 ent = otabg[a];
     const uint32_t w = ent.w;
@@ -2899,7 +2915,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
     uint32_t nsg = kSlotInvalid;  // pre-drawn placement of the next episode
     if (kNsgMode == 2) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     LaneRaw raw;
-    lane_issue(io.agents + (size_t)env * N + min(a, N - 1), raw);
+    lane_issue(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), raw);
     int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
     int sc[12];
     load_scal(io.scal, env, sc);
@@ -2927,13 +2943,12 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
     MAPF_STAMP(1);
     bool records_stored = false;
     if (full && !__any(act < 0 || act > 4))
-        records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg,
-                                                            io.agents + (size_t)env0 * N, kNsgMode == 1);
+        records_stored = step_body<K, LPE, MW, true, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, true, kNsgMode == 1);
     else
-        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, kNsgMode == 1);
-    if (!records_stored) {  // otherwise records and counters left from inside the body
-        if (full) store_lanes_coalesced(io.agents + (size_t)env0 * N, l.xpose, lane, st);
-        else if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        step_body<K, LPE, MW, false, kDual>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, false, kNsgMode == 1);
+    if (!records_stored) {  // otherwise agents and counters left from inside the body
+        if (full || is_agent)
+            store_lane(io.agents, io.bn8, (size_t)env * N + a, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
         if (env_ok && a == 0) store_scal(io.scal, env, sc);
     }
     MAPF_STAMP(8);
@@ -2983,40 +2998,52 @@ __device__ __forceinline__ void group_xchg(const uint32_t v, uint32_t (&o)[LPE -
     }
 }
 
-constexpr uint32_t kObsWDone = 256u, kObsWSuccess = 512u, kObsWDoReset = 1024u;  // for the aux wave (k_step3)
-
-// resolve_moves (same rule, same outcome) with the {old, target} pairs exchanged by DPP
+// resolve_moves (same rule, same outcome) without a table in LDS, without a loop and without a branch: the {old, target}
+// pairs travel by DPP, every lane works out who stands on its target and who else wants it, and then EVERY lane replays
+// the group's decisions in index order on one word per agent (broadcast inside the group by ds_swizzle: the LDS
+// crossbar, no memory access): agent j moves iff no lower-index occupant of its target stayed and no lower-index
+// contender got in (MA-env:502-526 is sequential; dependencies only point to lower indices).
+template <int J, int LPE>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {  // lane J of every lane group
+    constexpr int pattern = (J << 5) | (LPE == 8 ? 0x18 : 0x1C);  // bit mode: lane' = (lane & and_mask) | or_mask
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, pattern);
+}
 template <int LPE>
-__device__ __forceinline__ uint32_t resolve_moves_dpp(int lane, int a, uint32_t old, uint32_t tgt) {
-    using gm_t = typename GMask<LPE>::type;
+__device__ __forceinline__ uint32_t resolve_moves_dpp(int a, uint32_t old, uint32_t tgt) {
+    static_assert(LPE == 4 || LPE == 8, "written for groups of 4 or 8 lanes");
     uint32_t x[LPE - 1];
     group_xchg<LPE>(old | (tgt << 16), x);
-    gm_t occ_bit = 0, cont = 0;
-    const bool want = tgt != kNoCell;
+    uint32_t occ = 0, cont = 0;
 #pragma unroll
     for (int k = 1; k < LPE; k++) {
-        const gm_t bit = (gm_t)1 << (a ^ k);
-        occ_bit |= ((x[k - 1] & 0xFFFFu) == tgt) ? bit : 0;
-        cont |= ((x[k - 1] >> 16) == tgt) ? bit : 0;
+        const uint32_t bit = 1u << (a ^ k);
+        occ |= ((x[k - 1] & 0xFFFFu) == tgt) ? bit : 0u;
+        cont |= ((x[k - 1] >> 16) == tgt) ? bit : 0u;
     }
-    const gm_t below = ((gm_t)1 << a) - 1;
-    cont = want ? (cont & below) : 0;
-    const gm_t occ_low = occ_bit & below;
-    const bool occ_high = (occ_bit & ~below) != 0;
-    const gm_t dep = cont | occ_low;
-    bool resolved = !want, moved = false;
-    gm_t R = gballot_n<LPE>(resolved, lane), M = 0;
-#pragma unroll 1
-    for (int it = 0; it <= LPE; it++) {
-        if (__all(resolved)) break;
-        if (!resolved && (dep & ~R) == 0) {
-            moved = !(occ_high || (occ_low & ~M) != 0 || (cont & M) != 0);
-            resolved = true;
-        }
-        R = gballot_n<LPE>(resolved, lane);
-        M = gballot_n<LPE>(moved, lane);
+    const uint32_t below = (1u << a) - 1u;
+    // free to move as far as higher indices go: a target, and no higher-index agent standing on it (it has not had its
+    // turn yet).  Word of this agent: bits 0-7 lower-index occupants of the target (bit 8: cannot move at all),
+    // bits 16-23 lower-index contenders.
+    const bool ok = tgt != kNoCell && (occ & ~below) == 0;
+    const uint32_t mine = (ok ? (occ & below) : 0x100u) | ((cont & below) << 16);
+    uint32_t d[LPE];
+    d[0] = group_bcast<0, LPE>(mine);
+    d[1] = group_bcast<1, LPE>(mine);
+    d[2] = group_bcast<2, LPE>(mine);
+    d[3] = group_bcast<3, LPE>(mine);
+    if constexpr (LPE == 8) {
+        d[4] = group_bcast<4, LPE>(mine);
+        d[5] = group_bcast<5, LPE>(mine);
+        d[6] = group_bcast<6, LPE>(mine);
+        d[7] = group_bcast<7, LPE>(mine);
     }
-    return moved ? tgt : old;
+    uint32_t M = 0;  // who has moved
+#pragma unroll
+    for (int j = 0; j < LPE; j++) {
+        const uint32_t blocked = ((d[j] >> 16) & M) | ((d[j] & 0xFFFFu) & ~M);  // a contender got in | an occupant stayed
+        M |= blocked == 0 ? (1u << j) : 0u;
+    }
+    return ((M >> a) & 1u) ? tgt : old;
 }
 
 // what an agent's step means for its own flags, shared by the state wave and the aux wave of k_step3 (finite mode,
@@ -3050,10 +3077,187 @@ __device__ __forceinline__ AgentStep agent_step(const Lane &st, int act, uint32_
     return s;
 }
 
+// How the step ends for an env (MA-env:668-690 and the auto-reset), from what ALL three waves of k_step3 hold -- the new
+// cells, the goals, the step counter, the env's placement slot -- so that each of them decides for itself, identically,
+// and the state wave publishes nothing but the moves: success check before the step limit; a finished env is re-placed
+// from its pre-drawn slot (fast) or draws inline (slow); without a caller for the terminal observation the reset
+// observation takes its place (subst).
+struct EndDecision {
+    int term, trunc;
+    bool on_goal, done, do_reset, fast_reset, slow_reset, subst;
+};
+template <int LPE>
+__device__ __forceinline__ EndDecision decide_end(const Io &io, int N, int lane, uint32_t cur, uint32_t goal,
+                                                  int step_count, uint32_t nsg) {
+    EndDecision d;
+    d.on_goal = cur == goal;
+    d.term = d.trunc = 0;
+    if (__popcll(gballot<LPE>(d.on_goal, lane)) == N) {
+        d.term = 1;
+    } else if (step_count >= io.steps_per_episode) {
+        d.term = 1;
+        d.trunc = 1;
+    }
+    d.done = (d.term | d.trunc) != 0;
+    d.do_reset = d.done && io.auto_reset;
+    d.fast_reset = d.slow_reset = d.subst = false;
+    if (__builtin_expect(__any(d.do_reset), 0)) {
+        const bool slot_ok = gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
+        d.fast_reset = d.do_reset && slot_ok;
+        d.slow_reset = d.do_reset && !slot_ok;
+        d.subst = d.fast_reset && io.final_obs == nullptr;
+    }
+    return d;
+}
+// which tensor a group's observation goes to (0 io.obs, 1 io.final_obs, 2 nowhere) and the kObsW* flags of an entry
+__device__ __forceinline__ uint32_t obs_flags_for(const Io &io, const EndDecision &d, bool pressure_prev) {
+    int sel = io.obs ? 0 : 2;
+    uint32_t w = kObsWAgent | (pressure_prev ? kObsWPressure : 0u) | kObsWFast;
+    if (d.do_reset) sel = io.final_obs ? 1 : ((d.subst && io.obs) ? 0 : 2);
+    if (d.subst) w = (w & ~kObsWPressure) | kObsWFinal;
+    w |= (d.slow_reset ? kObsWReset : 0u) | ((d.fast_reset && !d.subst) ? kObsWResetFast : 0u);
+    return w | ((uint32_t)sel << kObsWSelShift);
+}
+
+// ---- wave 1 of k_step3 -------------------------------------------------------------------------------------------
+// The observation wave no longer idles until the moves are known.  Everything but the moves is there when its own loads
+// are: positions, goals, actions, the obstacle rows.  Before B1 it builds, per agent, the bit planes of a (V+2) x (V+2)
+// SUPERSET window centred on the cell the agent stands on (row stride 8 bits): obstacles, goals, own goal, the other
+// agents on their old cells, and for every lower-index agent j the two-bit difference D_j between "j on its old cell"
+// and "j on the cell it wants".  After B1 the state wave's verdict is one bit per agent (moved or not): the occupancy at
+// "time i" (MA-env:528: agents < i on their new cell, agents > i on their old one) is A0 xor the D_j of the movers, and
+// the agent's own move shifts the V x V window inside the superset.  An env whose episode is sure to end at the step
+// limit with a pre-drawn placement is handled the same way with the reset state as input (nobody moves): its reset
+// observation replaces the terminal one (step_body: subst).  Everything else -- an unpredicted ending (success), a slow
+// reset, a caller who wants the terminal observation -- takes the general path: the table walk of obs_wave_step.
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
+                                          const uint2 hot, const int act_real, const uint32_t nsg, const int step_count_in) {
+    constexpr int G = 64 / LPE;
+    using gm_t = typename GMask<LPE>::type;
+    const int grp = lane / LPE, a = lane % LPE;
+    const int N = K::N(p), H = io.H, V = K::V(p), sr = K::sr(p), S = V + 2;
+    const uint32_t flags = K::flags(p);
+    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
+    float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
+    const uint32_t pos_real = hot.x & 0xFFFFu, goal_real = hot.x >> 16;
+    const bool pressure_real = ((hot.y >> 16) & kFlagPressure) != 0;
+#ifndef MAPF_OBS_PRE
+#define MAPF_OBS_PRE 0
+#endif
+    constexpr bool kPre = MAPF_OBS_PRE != 0 && MW == 32;  // (the superset of wider windows does not fit 8 x 8 bits)
+
+    bool pred = false;
+    uint32_t pos_in = pos_real, goal_in = goal_real, cand = pos_real;
+    int dr = 0, dc = 0;
+    uint64_t obst = 0, A0 = 0, Gs = 0, own = 0, D[LPE - 1];
+    if (kPre) {
+        const bool slot_ok = gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
+        pred = io.auto_reset && io.final_obs == nullptr && step_count_in + 1 >= io.steps_per_episode && slot_ok;
+        pos_in = pred ? (nsg & 0xFFFFu) : pos_real;
+        goal_in = pred ? (nsg >> 16) : goal_real;
+        const int act_in = pred ? 0 : act_real;
+        const int r0s = (int)(pos_in >> 8) - sr - 1, c0s = (int)(pos_in & 255u) - sr - 1;
+        if (io.col_pad) {
+#pragma unroll
+            for (int d = 0; d < 7; d++)
+                if (d < S) obst |= (uint64_t)row_window_padded(myrows[r0s + d], c0s, S, io.col_pad) << (8 * d);
+        } else {
+#pragma unroll
+            for (int d = 0; d < 7; d++)
+                if (d < S) obst |= (uint64_t)row_window_wide(myrows[r0s + d], c0s, S) << (8 * d);
+        }
+        dr = (act_in == 1) ? -1 : ((act_in == 3) ? 1 : 0);
+        dc = (act_in == 2) ? 1 : ((act_in == 4) ? -1 : 0);
+        const int ctr = 8 * (sr + 1) + (sr + 1);
+        const bool want = act_in != 0 && ((obst >> ((ctr + 8 * dr + dc) & 63)) & 1ull) == 0;
+        cand = want ? (uint32_t)(((int)pos_in + (dr << 8) + dc) & 0xFFFF) : pos_in;
+        uint32_t xo[LPE - 1], xg[LPE - 1];
+        group_xchg<LPE>(pos_in | (cand << 16), xo);
+        group_xchg<LPE>(goal_in, xg);
+        auto bit8 = [&](uint32_t cell) -> uint64_t {  // the cell's bit in my superset window, or nothing
+            const int rr = (int)((cell >> 8) & 255u) - r0s, cc = (int)(cell & 255u) - c0s;
+            const bool in = max((unsigned)rr, (unsigned)cc) < (unsigned)S;
+            return in ? (1ull << ((8 * rr + cc) & 63)) : 0ull;
+        };
+        own = bit8(goal_in);
+        Gs = own;
+#pragma unroll
+        for (int k = 1; k < LPE; k++) {
+            const uint64_t bo = bit8(xo[k - 1] & 0xFFFFu), bc = bit8(xo[k - 1] >> 16);
+            A0 ^= bo;
+            Gs |= bit8(xg[k - 1]);
+            D[k - 1] = ((a ^ k) < a) ? (bo ^ bc) : 0ull;
+        }
+    }
+    wg_sync();  // B1: the moves
+    MAPF_STAMP_W1(11);
+    const uint4 ent = l.otab[lane];
+    const uint32_t cur = ent.y >> 16;
+    const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal_real, step_count_in + 1, nsg);
+    const bool special = dec.slow_reset || (dec.fast_reset && !dec.subst) || (dec.subst != pred);
+    if (!kPre || io.obs == nullptr || __builtin_expect(__any(special), 0)) {
+        // ---- general path: complete the entries (flags; a substituted env: everybody on its start, the new goals) and
+        //      walk them (obs_wave_step); word y's upper half (the real new cell) is the aux wave's and stays
+        const uint32_t w = obs_flags_for(io, dec, pressure_real);
+        const uint32_t rs = nsg, rs_pos = rs & 0xFFFFu;
+        uint4 mine = make_uint4(ent.x, ent.y, dec.fast_reset ? rs : 0u, w);
+        if (dec.subst) mine = make_uint4(rs_pos | (rs_pos << 16), (rs >> 16) | (cur << 16), rs, w);
+        l.otab[lane] = mine;
+        wave_lds_sync();
+        obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true);
+        return;
+    }
+#if MAPF_ABL == 1  // (ablation: the observation wave stops at B1)
+    return;
+#endif
+    // ---- fast path ----
+    const gm_t M = pred ? (gm_t)0 : gballot_n<LPE>(cur != pos_real, lane);
+    uint64_t A = A0;
+#pragma unroll
+    for (int k = 1; k < LPE; k++) A ^= ((M >> (a ^ k)) & 1u) ? D[k - 1] : 0ull;
+    const bool mv = ((M >> a) & 1u) != 0;
+    const int sh = 8 * (1 + (mv ? dr : 0)) + 1 + (mv ? dc : 0);
+    const uint32_t new_pos = mv ? cand : pos_in;
+    const uint64_t oa = obst | A;
+    const uint64_t g3 = own & ~oa;
+    const uint64_t g4 = Gs & ~(oa | own);
+    const uint64_t b0 = obst | g3;
+    const uint64_t b1 = (A & ~obst) | g3;
+    auto compact = [&](uint64_t x) -> WMask<32> {  // V x V window at offset sh of the superset -> row stride V
+        x >>= sh;
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32), m = (1u << V) - 1u;
+        uint32_t c = lo & m;
+        if (V > 1) c |= ((lo >> 8) & m) << V;
+        if (V > 2) c |= ((lo >> 16) & m) << (2 * V);
+        if (V > 3) c |= ((lo >> 24) & m) << (3 * V);
+        if (V > 4) c |= (hi & m) << (4 * V);
+        return WMask<32>{c};
+    };
+    const bool norm = (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
+    emit_obs_planes<K, 32, 5>(p, srow, compact(b0), compact(b1), compact(g4), compact(oa),
+                              goal_delta((int)((goal_in >> 8) & 255u) - (int)(new_pos >> 8), io.den_r, norm),
+                              goal_delta((int)(goal_in & 255u) - (int)(new_pos & 255u), io.den_c, norm), !pred && pressure_real);
+    wave_lds_sync();
+    MAPF_STAMP_W1(12);
+#if MAPF_ABL == 4  // (ablation: no observation stream)
+    return;
+#endif
+    flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
+    MAPF_STAMP_W1(13);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MAPF_STAMP_W1(14);
+#endif
+}
+
 // ---- wave 2 of k_step3 -------------------------------------------------------------------------------------------
+// Everything of the step that follows the moves and is not the observation: goal / reward logic (MA-env:538-563), lock
+// flags and detector (:577-606), intent blocking (:608-623), info (:627-656), termination outputs (:668-690), the state
+// image (all four planes, counters) incl. the image of a re-placed env, episode statistics, the MAY_FINISH hint.
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const Lds &l, unsigned char *aux_lds, const int lane,
-                                          const int env0, const int act, Lane &st, int *sc) {
+                                          const int env0, const int act, Lane &st, int *sc, const uint32_t nsg) {
     constexpr int G = 64 / LPE;
     using gm_t = typename GMask<LPE>::type;
     const int grp = lane / LPE, a = lane % LPE;
@@ -3063,16 +3267,19 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
     const bool dist_in_rec = lw <= 16;
+    const size_t idx = (size_t)env0 * N + lane;
+    const uint64_t *myrows = l.rows + grp * (io.H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
 
     MAPF_STAMP_W2(21);
     wg_sync();  // B1: the moves are published
     MAPF_STAMP_W2(22);
-    const uint4 ent = l.otab[lane];
-    const uint32_t w = ent.w, cur = ent.y >> 16;  // (word x is the observation wave's: a substituted entry carries the
-                                                 //  reset position there)
-    const bool done = (w & kObsWDone) != 0, do_reset = (w & kObsWDoReset) != 0;
-
+#if MAPF_ABL == 2  // (ablation: the aux wave stops at B1)
+    return;
+#endif
+    const uint32_t cur = l.otab[lane].y >> 16;  // (the rest of the entry is the observation wave's)
     sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
+    const EndDecision dec = decide_end<LPE>(io, N, lane, cur, st.goal, sc[MAPF_CTR_STEP_COUNT], nsg);
+    const bool done = dec.done, do_reset = dec.do_reset;
     const AgentStep as = agent_step(st, act, cur);
     const int goals_step = __popcll(gballot<LPE>(as.grs, lane));
     sc[MAPF_CTR_GOALS_REACHED_TOTAL] += goals_step;
@@ -3109,10 +3316,10 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     sc[MAPF_CTR_MAY_FINISH] = (gballot<LPE>(as.dist > 1, lane) == 0 ||
                                sc[MAPF_CTR_STEP_COUNT] + 1 >= io.steps_per_episode) ? 1 : 0;
 
-    // pair pass (MA-env:389-398 neighbour sets, :608-623 intent blocking) on DPP-exchanged entries
-    uint32_t xn[LPE - 1], xy[LPE - 1], xz[LPE - 1];
-    group_xchg<LPE>(cur, xn);
-    group_xchg<LPE>((as.reached ? 1u : 0u) | ((uint32_t)(delta + 256) << 1), xy);
+    // pair pass (MA-env:389-398 neighbour sets, :608-623 intent blocking) on DPP-exchanged words:
+    // xa = new cell | reached << 16 | (distance delta + 256) << 17,  xz = intended cell (+1,+1) or ~0 once reached
+    uint32_t xa[LPE - 1], xz[LPE - 1];
+    group_xchg<LPE>(cur | ((as.reached ? 1u : 0u) << 16) | ((uint32_t)(delta + 256) << 17), xa);
     group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
     const uint32_t mycell1 = cur + 0x0101u;
     gm_t nbr = 0;
@@ -3120,14 +3327,48 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     bool blocks = false;
 #pragma unroll
     for (int k = 1; k < LPE; k++) {
-        const int d = cell_l1(xn[k - 1], cur);
+        const int d = cell_l1(xa[k - 1] & 0xFFFFu, cur);
         const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);
         nbr |= isn ? ((gm_t)1 << (a ^ k)) : 0;
-        sum_biased += isn ? (int)(xy[k - 1] >> 1) : 0;
+        sum_biased += isn ? (int)(xa[k - 1] >> 17) : 0;
         blocks |= xz[k - 1] == mycell1;
     }
     const int sum_delta = delta + sum_biased - 256 * __popc((uint32_t)nbr);
     const bool blocking = as.reached && !as.moved && blocks;
+
+    // ---- what does not need the lock detector leaves first: rewards, per-agent info, done flags, the hot plane ----
+    {
+        const float term_reward = !done ? 0.0f : (!dec.trunc ? 1.0f : (dec.on_goal ? 0.0f : -1.0f));
+        const float reward = (as.grs ? 0.5f : 0.0f) + term_reward;
+        if (io.rewards) io.rewards[idx] = reward;
+        if (io.info_agent) {
+            uchar2 ia;
+            ia.x = blocking ? 1 : 0;
+            ia.y = as.grs ? 1 : 0;
+            reinterpret_cast<uchar2 *>(io.info_agent)[idx] = ia;
+        }
+        if (a == 0) {
+            if (io.terminated) io.terminated[env] = (uint8_t)dec.term;
+            if (io.truncated) io.truncated[env] = (uint8_t)dec.trunc;
+        }
+        Lane img;
+        img.pos = cur;
+        img.goal = st.goal;
+        img.start = st.start;
+        img.flags = (as.reached ? kFlagReached : 0) | (as.completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+        if (__builtin_expect(__any(dec.fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+            if (dec.fast_reset) {
+                img.start = nsg & 0xFFFFu;
+                img.goal = nsg >> 16;
+                img.pos = img.start;
+                img.flags = 0u;
+                slots_of(io.scal, io.B)[idx] = kSlotInvalid;  // consumed
+            }
+        }
+        // (an env that draws inline -- slow reset -- gets its hot plane from the state wave, which makes the draw)
+        if (!dec.slow_reset) store_lane_hot(io.agents, idx, img, agent_pass_bits(myrows, img.pos, io.col_pad, io.W));
+    }
+    MAPF_STAMP_W2(24);
 
     int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
     if (lock_on) {  // MA-env:400-438, as step_body
@@ -3194,13 +3435,21 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
             store_state16(io.scal + (size_t)(env0 + g) * kScalInts + j * 4, xs[lane]);
         }
     }
+    {   // the history planes (a re-placed env: _reset_lock_tracking MA-env:360-372, whichever wave places it)
+        Lane img = st;
+        if (do_reset) {
+            img.moved = img.failed = img.progress = 0ull;
+            img.dist = make_uint4(0, 0, 0, 0);
+        }
+        store_lane_hist(io.agents, io.bn8, idx, img);
+    }
     MAPF_STAMP_W2(30);
     // episode statistics (callbacks.py:236-345), as step_body
     if (__builtin_expect(__any(done), 0)) {
         if (done && a == 0) {
             int *acc = p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC;
             atomicAdd(acc + MAPF_ACC_EPISODES, 1);
-            if (w & kObsWSuccess) atomicAdd(acc + MAPF_ACC_SUCCESSES, 1);
+            if (dec.term && !dec.trunc) atomicAdd(acc + MAPF_ACC_SUCCESSES, 1);
             atomicAdd(acc + MAPF_ACC_GOALS_REACHED, sc[MAPF_CTR_GOALS_REACHED_TOTAL]);
             atomicAdd(acc + MAPF_ACC_BLOCKING_COUNT, sc[MAPF_CTR_BLOCKING_COUNT]);
             atomicAdd(acc + MAPF_ACC_DEADLOCK_COUNT, sc[MAPF_CTR_DEADLOCK_EVENTS]);
@@ -3211,167 +3460,56 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
             atomicAdd(acc + MAPF_ACC_EPISODE_STEPS, sc[MAPF_CTR_STEP_COUNT]);
         }
     }
-    if (__any((w & kObsWReset) != 0)) wg_sync();  // B2 (the state wave's slow reset; all waves of the workgroup meet)
+    if (__builtin_expect(__any(dec.slow_reset), 0)) wg_sync();  // B2 (the state wave's slow reset; all waves of the workgroup meet)
 }
 
-// ---- wave 0 of k_step3 (FAST workgroups) -------------------------------------------------------------------------
+// ---- wave 0 of k_step3 (FAST workgroups): the move phase, nothing else on its path -----------------------------------
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                            const int act, Lane &st, const int step_count_in, uint32_t nsg,
-                                            const bool nsg_lazy) {
+                                            const int act, const uint2 hot, const int step_count_in, uint32_t nsg) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const int env = env0 + grp;
     const int N = K::N(p), H = io.H, W = io.W;
-    const uint32_t flags = K::flags(p);
-    const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
-    const bool dist_in_rec = K::lw(p) <= 16;
-    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;  // (l.rows: this wave's own copy)
-    const int step_count = step_count_in + 1;
+    const uint32_t old = hot.x & 0xFFFFu, goal = hot.x >> 16, pass = hot.y >> 24;
 
-    // ---- move phase (MA-env:502-526), as step_body ----
-    const uint32_t old = st.pos;
-    const int r_old = (int)(old >> 8), c_old = (int)(old & 255u);
+    // ---- move phase (MA-env:502-526): "inside the grid and no obstacle" is the agent's pass bit for the action ----
     const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
     const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
-    const int tr = r_old + dr, tc = c_old + dc;
-    const uint64_t trow = myrows[tr];
-    const bool col_ok = io.col_pad != 0 || (tc >= 0 && tc < W);
-    const bool want = act != 0 && col_ok && !((trow >> ((tc + io.col_pad) & 63)) & 1ull);
-    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    const bool want = act != 0 && ((pass >> ((act - 1) & 3)) & 1u) != 0;
+    const uint32_t tgt = want ? (uint32_t)(((int)old + (dr << 8) + dc) & 0xFFFF) : kNoCell;
     MAPF_STAMP(16);
     uint32_t cur = old;
-    if (__any(want)) cur = resolve_moves_dpp<LPE>(lane, a, old, tgt);
+    if (__any(want)) cur = resolve_moves_dpp<LPE>(a, old, tgt);
     MAPF_STAMP(2);
-
-    // ---- termination (MA-env:668-690): success check precedes the step-limit check ----
-    const bool on_goal = cur == st.goal;
-    int term = 0, trunc = 0;
-    float term_reward = 0.0f;
-    {
-        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
-        if (n_on_goal == N) {
-            term_reward = 1.0f;
-            term = 1;
-        } else if (step_count >= io.steps_per_episode) {
-            if (!on_goal) term_reward = -1.0f;
-            term = 1;
-            trunc = 1;
-        }
-    }
-    const bool done = (term | trunc) != 0;
-    const bool do_reset = done && io.auto_reset;
-    const bool want_any_obs = io.obs || io.final_obs;
-    const bool pressure_prev = (st.flags & kFlagPressure) != 0;
-    int sel = io.obs ? 0 : 2;
-    uint32_t obs_w0 = kObsWAgent | (pressure_prev ? kObsWPressure : 0u) | kObsWFast | (done ? kObsWDone : 0u) |
-                      ((term && !trunc) ? kObsWSuccess : 0u) | (do_reset ? kObsWDoReset : 0u);
-    bool fast_reset = false, slow_reset = false, subst = false;
-    if (__builtin_expect(__any(do_reset), 0)) {
-        if (nsg_lazy) nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
-        const bool slot_ok = gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
-        // (without observations there is no observation wave at the barriers: such launches take the slow reset, which
-        //  needs none when nothing is observed)
-        fast_reset = do_reset && slot_ok;
-        slow_reset = do_reset && !fast_reset;
-        subst = fast_reset && io.final_obs == nullptr;
-        if (do_reset) sel = io.final_obs ? 1 : ((subst && io.obs) ? 0 : 2);
-        if (subst) obs_w0 = (obs_w0 & ~kObsWPressure) | kObsWFinal;
-        obs_w0 |= (slow_reset ? kObsWReset : 0u) | ((fast_reset && !subst) ? kObsWResetFast : 0u);
-    }
-    obs_w0 |= (uint32_t)sel << kObsWSelShift;
-    {
-        // x old | new << 16, y goal (low half: the observation wave masks it) | the real new cell << 16 (aux wave),
-        // z reset placement, w kObsW* flags
-        uint4 e = make_uint4(old | (cur << 16), (st.goal & 0xFFFFu) | (cur << 16), 0u, obs_w0);
-        if (__builtin_expect(__any(fast_reset), 0)) {
-            const uint32_t rs = nsg, rs_pos = rs & 0xFFFFu;
-            if (fast_reset) e.z = rs;
-            if (subst) e = make_uint4(rs_pos | (rs_pos << 16), (rs >> 16) | (cur << 16), rs, obs_w0);
-        }
-        l.otab[lane] = e;
-    }
+    // ---- publish the moves: x old | new << 16, y goal | new << 16 (the aux wave reads the new cell there), z the
+    //      placement slot word; how the step ends every wave decides for itself (decide_end) ----
+    l.otab[lane] = make_uint4(old | (cur << 16), goal | (cur << 16), nsg, 0u);
     wg_sync();  // B1
     MAPF_STAMP(19);
-
-    // ---- goal / reward logic, lock flags of the record ----
-    const AgentStep as = agent_step(st, act, cur);
-    float reward = as.grs ? 0.5f : 0.0f;
-    reward += term_reward;
-    if (lock_on) {
-        st.moved = (st.moved << 1) | (as.moved ? 1ull : 0ull);
-        st.failed = (st.failed << 1) | (as.failed ? 1ull : 0ull);
-        st.progress = (st.progress << 1) | (as.progress ? 1ull : 0ull);
-        if (dist_in_rec) {
-            st.dist.w = (st.dist.w << 8) | (st.dist.z >> 24);
-            st.dist.z = (st.dist.z << 8) | (st.dist.y >> 24);
-            st.dist.y = (st.dist.y << 8) | (st.dist.x >> 24);
-            st.dist.x = (st.dist.x << 8) | (uint32_t)as.dist;
-        }
-    }
-    // intent blocking (MA-env:608-623): some not-yet-reached agent intended to enter my cell
-    uint32_t xz[LPE - 1];
-    group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
-    const uint32_t mycell1 = cur + 0x0101u;
-    bool blocks = false;
-#pragma unroll
-    for (int k = 1; k < LPE; k++) blocks |= xz[k - 1] == mycell1;
-    const bool blocking = as.reached && !as.moved && blocks;
-    MAPF_STAMP(3);
-
-    if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
-    if (io.info_agent) {
-        uchar2 ia;
-        ia.x = blocking ? 1 : 0;
-        ia.y = as.grs ? 1 : 0;
-        reinterpret_cast<uchar2 *>(io.info_agent)[(size_t)env * N + a] = ia;
-    }
-    if (a == 0) {
-        if (io.terminated) io.terminated[env] = (uint8_t)term;
-        if (io.truncated) io.truncated[env] = (uint8_t)trunc;
-    }
-    MAPF_STAMP(17);
-    st.pos = cur;
-    st.flags = (as.reached ? kFlagReached : 0) | (as.completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
-    AgentRec *rec0 = io.agents + (size_t)env0 * N;
-    if (!__builtin_expect(__any(slow_reset), 0)) {
-        Lane img = st;
-        if (__builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
-            if (fast_reset) {
-                img.start = nsg & 0xFFFFu;
-                img.goal = nsg >> 16;
-                img.pos = img.start;
-                img.flags = 0u;
-                img.moved = img.failed = img.progress = 0ull;
-                img.dist = make_uint4(0, 0, 0, 0);
-                slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;  // consumed
-            }
-        }
-        store_lanes_coalesced(rec0, l.xpose, lane, img);
-        MAPF_STAMP(18);
-        return;
-    }
-    // ---- an env of the wave ends its episode without a pre-drawn placement: draw inline (reset_groups), B2 inside ----
-    {
-        if (fast_reset) {  // the other re-placed groups of the wave
-            st.start = nsg & 0xFFFFu;
-            st.goal = nsg >> 16;
-            st.pos = st.start;
-            st.flags = 0u;
-            st.moved = st.failed = st.progress = 0ull;
-            st.dist = make_uint4(0, 0, 0, 0);
-            slots_of(io.scal, io.B)[(size_t)env * N + a] = kSlotInvalid;
-            nsg = kSlotInvalid;
-        }
-        int sc_unused[12];  // (the aux wave owns the counters; it stores their reset image)
+#if MAPF_ABL == 3  // (ablation: the state wave stops at B1)
+    return;
+#endif
+    // ---- an env of the wave ends its episode without a pre-drawn placement (rare): draw inline (reset_groups, B2 inside)
+    const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal, step_count_in + 1, nsg);
+    if (__builtin_expect(__any(dec.slow_reset), 0)) {
+        const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
+        Lane st;
+        st.pos = cur;
+        st.goal = goal;
+        st.start = hot.y & 0xFFFFu;
+        st.flags = 0u;
+        st.moved = st.failed = st.progress = 0ull;
+        st.dist = make_uint4(0, 0, 0, 0);
+        int sc_unused[12];  // (the aux wave owns the counters and the history planes; it stores their reset image)
 #pragma unroll
         for (int k = 0; k < 12; k++) sc_unused[k] = 0;
         wave_lds_sync();
-        (void)want_any_obs;
-        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, true, true, slow_reset, st,
+        reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, true, true, dec.slow_reset, st,
                                  sc_unused, io.obs != nullptr, nsg, true);  // B2: the aux wave is always there
-        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, G, slow_reset ? 0 : 2);
-        store_lanes_coalesced(rec0, l.xpose, lane, st);
+        if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, G, dec.slow_reset ? 0 : 2);
+        if (dec.slow_reset)
+            store_lane_hot(io.agents, (size_t)env0 * N + lane, st, agent_pass_bits(myrows, st.pos, io.col_pad, W));
     }
 }
 
@@ -3387,82 +3525,108 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
     const int env0 = (int)blockIdx.x * G;
-    const int ngroups = min(G, io.B - env0);
     const int N = K::N(p);  // == LPE
+    const int ngroups = min(G, io.B - env0);
     const bool full = ngroups == G;  // wave-uniform
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
+    const size_t idx = (size_t)env * N + a;
     __builtin_amdgcn_s_setprio(2);
 
+    // every wave reads the actions: FAST (full workgroup, no invalid action) is decided by each of them from the same bytes
     if (wv == 1) {
-        // ---- observation wave: as in k_step, minus B0 and minus the draw slices ----
+        // ---- observation wave ----
         RowRegs rr;
         rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);
+        const uint2 hot1 = io.agents[idx];
+        int act1 = (int)io.actions[idx];
+        const uint32_t nsg1 = slots_of(io.scal, io.B)[idx];
+        const int step1 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wave_lds_sync();
         MAPF_STAMP_W1(10);
-        if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+        act1 = env_ok ? act1 : 0;
+        const bool fast3 = full && !__any(act1 < 0 || act1 > 4);
+        if (__builtin_expect(!fast3, 0)) {  // the two-wave code
+            wg_sync();  // B0
+            if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
+            return;
+        }
+        if (io.obs || io.final_obs) obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, act1, nsg1, step1);
+        else wg_sync();  // B1 (the other waves read the rows behind it)
         return;
     }
 
-    // ---- waves 0 and 2: agent record, action (both decide FAST from it), and what each of them owns ----
-    RowRegs rr;
+    // ---- waves 0 and 2 ----
     LaneRaw raw;
-    lane_issue(io.agents + (size_t)env * N + a, raw);
-    int act = (int)io.actions[(size_t)env * N + a];
-    if (wv == 0) rows_issue<LPE>(io.grid_rows, io.H, lane, env0, ngroups, rr);  // the state wave's own copy of the rows
+    raw.h = io.agents[idx];
+    int act = (int)io.actions[idx];
     int sc[12];
-    uint32_t nsg = kSlotInvalid;
+    uint32_t nsg = slots_of(io.scal, io.B)[idx];
     DrawReq dreq;
-    constexpr bool kSpec = WPS == 0;
     if (wv == 0) {
         sc[0] = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
-        if (kSpec) nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
+        // for the background draw (below): the env's hint (same 64 bytes as the step counter); its slot word 0 is lane
+        // 0's nsg.  What a slice reads beyond that is fetched after B1 (this wave has the time; ahead of B1 every
+        // byte delays the loads the move phase waits for)
+        dreq.hint = io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH];
+        dreq.pop = 2 * N + 1;
+        dreq.sv[0] = dreq.sv[1] = 0;
+        dreq.rq = make_uint4(0, 0, 0, 0);
     } else {
+        lane_issue_hist(io.agents, io.bn8, idx, raw);
         load_scal(io.scal, env, sc);
-        draw_request_head<K, LPE, kSpec>(io, N, a, env, dreq);
     }
     __builtin_amdgcn_sched_barrier(0);
     warm_scalar_cache(pp, tail);
     __builtin_amdgcn_sched_barrier(0);
-    Lds l = carve_lds(io, lds_raw);
+    const Lds l = carve_lds(io, lds_raw);
+    unsigned char *aux_lds = lds_raw + io.lds_map_off;  // (k_step3: 1 KiB for the aux wave's info / counter staging)
+    const bool is_agent = env_ok;  // (N == LPE)
+    act = (full || is_agent) ? act : 0;
 #ifdef MAPF_STAMPS
-    if (wv == 0) {  // (experiment: when do the first 16 bytes of the records and the actions arrive?)
-        asm volatile("" ::"v"(raw.q0.x), "v"(act));
-        MAPF_STAMP(4);
-        asm volatile("" ::"v"(raw.q2.x));
-        MAPF_STAMP(5);
+    if (wv == 0) {
+        asm volatile("" ::"v"(raw.h.x), "v"(act));
+        MAPF_STAMP(0);
     }
 #endif
-    unsigned char *extra = lds_raw + io.lds_map_off;  // (k_step3: the state wave's rows, then 1 KiB for the aux wave)
-    const int rows_bytes = ((G * (io.H + 2 * kRowPad) * 8) + 15) & ~15;
-    if (wv == 0) {
-        l.rows = reinterpret_cast<uint64_t *>(extra);
-        rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
-        wave_lds_sync();
-    }
-    const bool is_agent = env_ok;  // (N == LPE)
-    Lane st;
-    lane_unpack(raw, full || is_agent, st);
-    act = (full || is_agent) ? act : 0;
     const bool fast3 = full && !__any(act < 0 || act > 4);
-    MAPF_STAMP(0);
-    MAPF_STAMP(1);
     if (__builtin_expect(!fast3, 0)) {
         // ---- a ragged last workgroup or an invalid action: the two-wave code of k_step ----
         if (wv == 2) return;  // before any barrier
+        lane_issue_hist(io.agents, io.bn8, idx, raw);
         load_scal(io.scal, env, sc);
-        nsg = slots_of(io.scal, io.B)[(size_t)env * N + a];
-        step_body<K, LPE, MW, false, true>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, nullptr, false);
-        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        Lane st;
+        lane_unpack(raw, is_agent, st);
+        wg_sync();  // B0: the observation wave's rows
+        step_body<K, LPE, MW, false, true>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, false, false);
+        if (is_agent)
+            store_lane(io.agents, io.bn8, idx, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
         if (env_ok && a == 0) store_scal(io.scal, env, sc);
         return;
     }
     if (wv == 0) {
-        state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, st, sc[0], nsg, !kSpec);
+        MAPF_STAMP(1);
+        state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, raw.h, sc[0], nsg);
+        // The background draw of the next placement (draw_slice), one slice per launch, runs HERE: this wave has nothing
+        // else to do once the moves are out, and its inputs came with the wave's first loads.  (The window before B1,
+        // where round 2 ran it in the observation wave, closed when B1 moved from 5.5 k to under 3 k cycles.)
+        {
+            dreq.w0 = group_bcast<0, LPE>(nsg);
+            const int d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
+            if (__builtin_expect(__any(d_stage != 0), 0)) {
+                MAPF_STAMP(4);
+                draw_slice<K, LPE>(p, io, l.scratch, lane, env, d_stage, dreq);
+#ifdef MAPF_STAMPS
+                int run = 0;
+                for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
+                if (p.dbg && threadIdx.x == 0) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
+#endif
+            }
+        }
         MAPF_STAMP(8);
 #ifdef MAPF_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3472,17 +3636,11 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         return;
     }
     // ---- aux wave ----
-    dreq.hint = sc[MAPF_CTR_MAY_FINISH];
-    const int d_stage = draw_request_body<K, LPE, kSpec>(p, io, N, a, env, true, dreq);
-    aux3_wave<K, LPE, MW>(p, io, l, extra + rows_bytes, lane, env0, act, st, sc);
-    if (__builtin_expect(__any(d_stage != 0), 0)) draw_slice<K, LPE>(p, io, l.scratch, lane, env, d_stage, dreq);
+    Lane st;
+    lane_unpack(raw, true, st);
+    aux3_wave<K, LPE, MW>(p, io, l, aux_lds, lane, env0, act, st, sc, nsg);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    {
-        int run = 0;
-        for (int k = 1; k <= kDrawSlices; k++) run = __any(d_stage == k) ? k : run;
-        if (p.dbg && threadIdx.x == 128) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = run;
-    }
 #endif
     MAPF_STAMP_W2(31);
 }
@@ -3571,7 +3729,7 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
     const bool is_agent = env_ok && a < N;
 
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), full || is_agent, st);
+    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), full || is_agent, st);
     int sc[12];
     load_scal(io.scal, env, sc);
     // a pre-drawn placement serves the env's first reset of this launch; later ones draw inline (no sampler here)
@@ -3620,7 +3778,8 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
             step_body<K, LPE, MW, false, kDual>(p, it, with_parity(l, t), lane, env0, ngroups, act, st, sc, nsg);
         wave_lds_sync();  // this wave's staging / table regions are reused by the next step
     }
-    if (full || is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (full || is_agent)
+        store_lane(io.agents, io.bn8, (size_t)env * N + a, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);
 }
 
@@ -3633,7 +3792,8 @@ __global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *_
 // LDS staging holds one row of H*W + 5N floats per env.
 // ================================================================================================
 struct CteIo {
-    AgentRec *agents;
+    uint2 *agents;  // plane 0 of the agent state
+    uint32_t bn8;
     int *scal;
     const uint64_t *grid_rows;
     int B, H, W, steps_per_episode;
@@ -3779,7 +3939,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     const int row_len = io.H * io.W + 5 * N;
     load_rows_to_lds<LPE>(io.grid_rows, io.H, lrows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
     if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
@@ -3795,7 +3955,8 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
         flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
     }
     if (do_reset) {
-        if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+        if (is_agent)
+            store_lane(io.agents, io.bn8, (size_t)env * N + a, st, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
         if (a == 0) {
             int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
             sp[0] = make_int4(0, 0, 0, 0);  // step_count, -, _episode_blocking_count, -
@@ -3847,7 +4008,7 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
     }
 
     Lane st;
-    load_lane(io.agents + (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
     int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
     wg_sync();  // B0
@@ -3962,7 +4123,7 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
             flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
         }
     }
-    if (is_agent) store_lane(io.agents + (size_t)env * N + a, st);
+    if (is_agent) store_lane(io.agents, io.bn8, (size_t)env * N + a, st, myrows, io.col_pad, io.W);
     if (env_ok && a == 0) {
         int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
         sp[0] = make_int4(step_count, 0, blocking_keep, 0);

@@ -91,7 +91,8 @@ struct mapf_engine {
     std::vector<uint64_t> h_rows;  // host copy of the obstacle rows (mapf_set_state validates injected positions against it)
     std::string err;
     // device allocations
-    AgentRec *d_agents = nullptr;
+    uint2 *d_agents = nullptr;  // the four planes of the agent state (mapf_kernels.inl: agent_plane_off)
+    uint32_t bn8 = 0;           // agent_plane_stride(B, N)
     int *d_scal = nullptr;
     int16_t *d_ring = nullptr;
     uint64_t *d_rng = nullptr;
@@ -167,7 +168,7 @@ int pick_lpe(int n) {
 enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 
 // the step kernels take the head of Io as individual (preloadable) arguments
-#define IO_HEAD_ARGS(io) (io).agents, (io).scal, (io).grid_rows, (io).actions, (io).B, (io).H, (io).W, (io).col_pad, \
+#define IO_HEAD_ARGS(io) (io).agents, (io).scal, (io).grid_rows, (io).actions, (io).B, (io).H, (io).W, (io).bn8, \
                          static_cast<const IoTail &>(io)
 
 template <int LPE, int MW>
@@ -210,7 +211,8 @@ template <class K, int LPE, int MW>
 hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     if constexpr (K::kSlicedDraw) {
         if (e->three_wave)
-            LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks), dim3(192), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
+            LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(192), e->lds_bytes, s, e->d_params,
+                           IO_HEAD_ARGS(io));
     }
     if constexpr (LPE < 32) {
         if (e->dense)
@@ -396,7 +398,7 @@ hipError_t launch_jit_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     const Params *pp = e->d_params;
     IoTail tail = static_cast<const IoTail &>(io);
     Io h = io;
-    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.col_pad, &tail};
+    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.bn8, &tail};
     return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, step_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
 }
 hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
@@ -404,7 +406,7 @@ hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mo
     IoTail tail = static_cast<const IoTail &>(io);
     Io h = io;
     ManyPolicy pl = pol;
-    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.col_pad, &tail, &T, &obs_mode, &pl};
+    void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.bn8, &tail, &T, &obs_mode, &pl};
     return hipModuleLaunchKernel(e->jit_many, e->blocks, 1, 1, many_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
 }
 
@@ -450,6 +452,69 @@ static hipError_t invalidate_slots(mapf_engine *e) {
 // (conservative: the sampler skips the env for one step, the next step writes the real hint).
 static hipError_t force_may_finish(mapf_engine *e) {
     return hipMemset2D(e->d_scal + MAPF_CTR_MAY_FINISH, kScalInts * sizeof(int), 1, sizeof(int), (size_t)e->p.B);
+}
+
+// Host image of the agent state <-> the device planes (mapf_kernels.inl: agent_plane_off).
+static int download_agents(mapf_engine *e, std::vector<AgentRec> &recs) {
+    const size_t BN = (size_t)e->p.B * e->p.N;
+    std::vector<unsigned char> raw(agent_state_bytes(e->bn8));
+    HIP_TRY(e, hipMemcpy(raw.data(), e->d_agents, raw.size(), hipMemcpyDeviceToHost));
+    const uint32_t *p0 = reinterpret_cast<const uint32_t *>(raw.data() + agent_plane_off(0, e->bn8));
+    const uint32_t *p1 = reinterpret_cast<const uint32_t *>(raw.data() + agent_plane_off(1, e->bn8));
+    const uint32_t *p2 = reinterpret_cast<const uint32_t *>(raw.data() + agent_plane_off(2, e->bn8));
+    const uint32_t *p3 = reinterpret_cast<const uint32_t *>(raw.data() + agent_plane_off(3, e->bn8));
+    recs.resize(BN);
+    for (size_t i = 0; i < BN; i++) {
+        AgentRec &r = recs[i];
+        r.w0 = p0[2 * i];
+        r.w1 = p0[2 * i + 1];
+        r.moved = (uint64_t)p1[4 * i] | ((uint64_t)p1[4 * i + 1] << 32);
+        r.failed = (uint64_t)p1[4 * i + 2] | ((uint64_t)p1[4 * i + 3] << 32);
+        r.progress = (uint64_t)p2[4 * i] | ((uint64_t)p2[4 * i + 1] << 32);
+        r.dist[0] = p2[4 * i + 2];
+        r.dist[1] = p2[4 * i + 3];
+        r.dist[2] = p3[2 * i];
+        r.dist[3] = p3[2 * i + 1];
+    }
+    return MAPF_OK;
+}
+// the pass bits of w1 (which neighbours of the position the grid lets an agent step on) are recomputed here from the
+// host copy of the obstacle rows: every writer of a position keeps them current (agent_pass_bits on the device)
+static uint32_t host_pass_bits(const mapf_engine *e, int b, uint32_t cell) {
+    if (!e->grids_set) return 0;
+    const int H = e->p.H, W = e->p.W, pad = e->col_pad;
+    const int r = (int)(cell >> 8), c = (int)(cell & 255u);
+    auto blocked = [&](int rr, int cc) -> uint32_t {
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) return 1u;
+        return (uint32_t)((e->h_rows[(size_t)b * H + rr] >> (cc + pad)) & 1ull);
+    };
+    return (blocked(r - 1, c) | (blocked(r, c + 1) << 1) | (blocked(r + 1, c) << 2) | (blocked(r, c - 1) << 3)) ^ 15u;
+}
+static int upload_agents(mapf_engine *e, const std::vector<AgentRec> &recs) {
+    const size_t BN = (size_t)e->p.B * e->p.N;
+    const int N = e->p.N;
+    std::vector<unsigned char> raw(agent_state_bytes(e->bn8), 0);
+    uint32_t *p0 = reinterpret_cast<uint32_t *>(raw.data() + agent_plane_off(0, e->bn8));
+    uint32_t *p1 = reinterpret_cast<uint32_t *>(raw.data() + agent_plane_off(1, e->bn8));
+    uint32_t *p2 = reinterpret_cast<uint32_t *>(raw.data() + agent_plane_off(2, e->bn8));
+    uint32_t *p3 = reinterpret_cast<uint32_t *>(raw.data() + agent_plane_off(3, e->bn8));
+    for (size_t i = 0; i < BN; i++) {
+        const AgentRec &r = recs[i];
+        p0[2 * i] = r.w0;
+        p0[2 * i + 1] = (r.w1 & 0x00FFFFFFu) | (host_pass_bits(e, (int)(i / N), r.w0 & 0xFFFFu) << 24);
+        p1[4 * i] = (uint32_t)r.moved;
+        p1[4 * i + 1] = (uint32_t)(r.moved >> 32);
+        p1[4 * i + 2] = (uint32_t)r.failed;
+        p1[4 * i + 3] = (uint32_t)(r.failed >> 32);
+        p2[4 * i] = (uint32_t)r.progress;
+        p2[4 * i + 1] = (uint32_t)(r.progress >> 32);
+        p2[4 * i + 2] = r.dist[0];
+        p2[4 * i + 3] = r.dist[1];
+        p3[2 * i] = r.dist[2];
+        p3[2 * i + 1] = r.dist[3];
+    }
+    HIP_TRY(e, hipMemcpy(e->d_agents, raw.data(), raw.size(), hipMemcpyHostToDevice));
+    return MAPF_OK;
 }
 
 extern "C" {
@@ -593,7 +658,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         if (e->special && N > 16 && !e->use_map) e->special = 0;
     }
     // k_step3: the specialised finite shapes with full groups of 4 or 8 lanes, while a launch has at most three waves per
-    // SIMD (three waves per workgroup: beyond that the two-wave kernel's 128-register build is the one that fits)
+    // SIMD (three waves per workgroup: beyond that the two-wave kernel's 128-register build is the one that fits).
     if (e->special && !e->sampler_blocks && !cte && (N == 4 || N == 8) && lpe == N &&
         !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC))) {
         int cus = 0;
@@ -603,8 +668,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = atoi(f) != 0;  // test / A-B knob
         if (e->three_wave) {
             e->dense = 0;
-            e->lds_map_off = e->lds_bytes;  // (no cell map at these widths) the state wave's rows, 1 KiB for the aux wave
-            e->lds_bytes += rows_bytes + 1024;
+            e->lds_map_off = e->lds_bytes;  // (no cell map at these widths) 1 KiB for the aux wave's info / counter staging
+            e->lds_bytes += 1024;
         }
     }
     if (e->sampler_blocks) {  // the sampler workgroups of a k_step launch have their own LDS layout
@@ -642,7 +707,8 @@ static int alloc_device_state(mapf_engine *e) {
     const int B = p.B, N = p.N, H = p.H;
     ON_DEVICE(e);
     const size_t BN = (size_t)B * N;
-    HIP_TRY(e, hipMalloc(&e->d_agents, BN * sizeof(AgentRec)));
+    e->bn8 = agent_plane_stride(B, N);
+    HIP_TRY(e, hipMalloc(&e->d_agents, agent_state_bytes(e->bn8)));
     // env scalars [B][16] followed by the next-episode placement slots [B][N] (slots_of(): the step kernel reaches
     // them from its preloaded arguments)
     // ... and by the env streams and free-cell counts (streams_of / free_counts_of)
@@ -659,7 +725,7 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMalloc(&e->d_free_cells, (size_t)B * p.HW * sizeof(uint16_t)));
     HIP_TRY(e, hipMalloc(&e->d_free_rank, (size_t)B * p.HW * sizeof(uint16_t)));
     HIP_TRY(e, hipMalloc(&e->d_err, 4 * sizeof(int)));
-    HIP_TRY(e, hipMemset(e->d_agents, 0, BN * sizeof(AgentRec)));
+    HIP_TRY(e, hipMemset(e->d_agents, 0, agent_state_bytes(e->bn8)));
     HIP_TRY(e, hipMemset(e->d_scal, 0, scal_bytes));
     HIP_TRY(e, hipMemset(reinterpret_cast<char *>(e->d_scal) + scal_bytes, 0xFF, slot_bytes));  // kSlotInvalid
     HIP_TRY(e, hipMemset(e->d_vis_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
@@ -740,6 +806,13 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
     HIP_TRY(e, invalidate_slots(e));
     e->h_rows = rows;
     e->grids_set = true;
+    {   // the agents' pass bits are a function of the grid (upload_agents recomputes them)
+        HIP_TRY(e, hipDeviceSynchronize());
+        std::vector<AgentRec> recs;
+        int rc = download_agents(e, recs);
+        if (rc == MAPF_OK) rc = upload_agents(e, recs);
+        if (rc != MAPF_OK) return rc;
+    }
     return MAPF_OK;
 }
 
@@ -757,8 +830,11 @@ int mapf_get_state(mapf_handle e, mapf_state *out) {
     const size_t BN = (size_t)B * N;
     ON_DEVICE(e);
     HIP_TRY(e, hipDeviceSynchronize());
-    std::vector<AgentRec> recs(BN);
-    HIP_TRY(e, hipMemcpy(recs.data(), e->d_agents, BN * sizeof(AgentRec), hipMemcpyDeviceToHost));
+    std::vector<AgentRec> recs;
+    {
+        const int rc = download_agents(e, recs);
+        if (rc != MAPF_OK) return rc;
+    }
     for (size_t i = 0; i < BN; i++) {
         const AgentRec &r = recs[i];
         const uint32_t pos = r.w0 & 0xFFFFu, goal = r.w0 >> 16, start = r.w1 & 0xFFFFu, fl = (r.w1 >> 16) & 0xFFu;
@@ -830,8 +906,11 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
     const bool touch_recs = in->positions || in->goals || in->starts || in->reached || in->completed_once ||
                             in->pressure_prev || in->lock_history || (in->distance_ring && ring_in_rec);
     if (touch_recs) {
-        std::vector<AgentRec> recs(BN);
-        HIP_TRY(e, hipMemcpy(recs.data(), e->d_agents, BN * sizeof(AgentRec), hipMemcpyDeviceToHost));
+        std::vector<AgentRec> recs;
+        {
+            const int rc = download_agents(e, recs);
+            if (rc != MAPF_OK) return rc;
+        }
         auto pack = [&](const int16_t *v, size_t i, uint32_t &dst) -> bool {
             int r = v[2 * i], c = v[2 * i + 1];
             if (r < 0 || r >= H || c < 0 || c >= W) return false;
@@ -899,7 +978,10 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
                 }
             }
         }
-        HIP_TRY(e, hipMemcpy(e->d_agents, recs.data(), BN * sizeof(AgentRec), hipMemcpyHostToDevice));
+        {
+            const int rc = upload_agents(e, recs);
+            if (rc != MAPF_OK) return rc;
+        }
     }
     if (in->counters)
         HIP_TRY(e, hipMemcpy(e->d_scal, in->counters, (size_t)B * kScalInts * sizeof(int), hipMemcpyHostToDevice));
@@ -944,6 +1026,7 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.bn8 = e->bn8;
     io.use_map = e->use_map;
     io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
@@ -975,6 +1058,7 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.bn8 = e->bn8;
     io.use_map = e->use_map;
     io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
@@ -1014,6 +1098,7 @@ static int step_many_impl(mapf_handle e, int32_t T, const int8_t *actions, const
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.bn8 = e->bn8;
     io.use_map = e->use_map;
     io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
@@ -1074,6 +1159,7 @@ static CteIo make_cte_io(const mapf_engine *e) {
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.bn8 = e->bn8;
     io.steps_per_episode = e->p.steps_per_episode;
     io.lds_tab_off = e->p.lds_tab_off;
     io.lds_stage_off = e->p.lds_stage_off;
@@ -1144,6 +1230,7 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.H = e->p.H;
     io.W = e->p.W;
     io.col_pad = e->col_pad;
+    io.bn8 = e->bn8;
     io.use_map = e->use_map;
     io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;

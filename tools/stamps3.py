@@ -29,19 +29,21 @@ for t in range(130):
 torch.cuda.synchronize()
 info = env.launch_info()
 blocks, ROW = info["blocks"], 32
-rows = []
+rows, srows = [], []
 for t in range(20):
     env.step(acts[t % 64])
     buf = np.zeros((blocks + 4096) * ROW, dtype=np.uint64)
     n = env._lib.mapf_debug_stamps(env._h, buf.ctypes.data_as(C.c_void_p), buf.size)
     rows.append(buf[: blocks * ROW].reshape(blocks, ROW).astype(np.int64))
+    srows.append(buf[blocks * ROW: n].reshape(-1, ROW).astype(np.int64))
 full = np.stack(rows)
+samp = np.stack(srows)
 rel = full - full[:, :, 15:16]
 names = {4: "W0 first 16 B of records + actions", 5: "W0 whole records", 0: "W0 state in registers (stamp 0)", 16: "W0 target cell known", 2: "W0 moves resolved", 19: "W0 past B1", 3: "W0 goal logic + blocking done",
          17: "W0 rewards / flags issued", 18: "W0 records issued", 8: "W0 body done", 9: "W0 stores drained",
          10: "W1 rows in LDS", 11: "W1 past B1", 12: "W1 observation staged", 13: "W1 stream issued", 14: "W1 stream drained",
-         21: "W2 state in registers", 22: "W2 past B1", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
-order = [4, 5, 0, 16, 2, 19, 3, 17, 18, 8, 9, 10, 11, 12, 13, 14, 21, 22, 29, 30, 31]
+         21: "W2 state in registers", 22: "W2 past B1", 24: "W2 rewards / flags / hot plane issued", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
+order = [0, 16, 2, 19, 8, 9, 10, 11, 12, 13, 14, 21, 22, 24, 29, 30, 31]
 print(f"workload {name} ({'staggered' if stagger else 'synchronised'}): {blocks} workgroups x {info['threads']} threads; cycles after the state wave's entry")
 end = np.max(np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]]), axis=0)
 slow = end.argmax(axis=1)
@@ -54,9 +56,19 @@ for k in order:
 print(f"  workgroup end (last of the three)  median {np.median(end):7.0f}  p95 {np.percentile(end, 95):7.0f}   slowest workgroup {np.median(end.max(axis=1)):7.0f}")
 kind = full[:, :, 23]
 if (kind > 0).any():
-    print(f"  aux waves running a draw slice per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
+    print(f"  state waves running a draw slice per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
     for k in range(1, 8):
         m = kind == k
         if m.any():
-            dur = (full[:, :, 31] - full[:, :, 30])[m]
-            print(f"    slice {k}: info stored -> end, median {np.median(dur):6.0f}  p95 {np.percentile(dur, 95):6.0f}")
+            dur = (full[:, :, 8] - full[:, :, 4])[m]
+            end = (full[:, :, 8] - full[:, :, 15])[m]
+            print(f"    slice {k}: duration median {np.median(dur):6.0f}  p95 {np.percentile(dur, 95):6.0f}; ends at {np.median(end):6.0f} (p95 {np.percentile(end, 95):6.0f}) after entry")
+
+if samp.shape[1]:  # sampler workgroups (their own clock origin: only durations inside a wave mean something)
+    act = samp[:, :, 4] > 0
+    d01 = samp[:, :, 1] - samp[:, :, 0]
+    print(f"  sampler workgroups: {samp.shape[1]}, active per launch (median) {np.median(act.sum(axis=1)):.0f};  entry -> need known: median {np.median(d01):.0f}  p95 {np.percentile(d01, 95):.0f}")
+    if act.any():
+        d03 = (samp[:, :, 3] - samp[:, :, 0])[act]
+        d12 = (samp[:, :, 2] - samp[:, :, 1])[act]
+        print(f"  active sampler wave (wave 0 of its workgroup): draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f}), entry -> stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
