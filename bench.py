@@ -71,25 +71,117 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------------------------------
 # parent: python bench.py --gpus N without torchrun -> one fresh child per GPU
 # ------------------------------------------------------------------------------------------------------
-def launch_ranks(args) -> int:
+def _kfd_gpu_nodes():
+    """GPU nodes of the KFD topology, in node order, as dicts of their properties -- read from sysfs, so the parent
+    never opens the HIP runtime before it starts its ranks (a process that has initialised the GPU must not spawn /
+    exec the workers of this pool).  None when the topology is not readable."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        names = sorted(os.listdir(root), key=lambda n: int(n))
+    except (OSError, ValueError):
+        return None
+    nodes = []
+    for n in names:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(root, n, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue  # (a node this cgroup may not read is not ours)
+        if int(props.get("simd_count", "0")) > 0:
+            nodes.append(props)
+    return nodes
+
+
+def visible_gpu_count() -> int:
+    """GPUs this job may use, WITHOUT initialising HIP in this process: the *_VISIBLE_DEVICES list if one is set, else
+    the KFD topology in sysfs, else a disposable child process that asks torch and exits."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = _kfd_gpu_nodes()
+    if nodes is not None:
+        return len(nodes)
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError):
+        return 0
+
+
+def _cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.extend(range(int(a), int(b) + 1))
+        elif part:
+            cpus.append(int(part))
+    return cpus
+
+
+def rank_cpu_sets(world: int):
+    """One CPU set per local rank: the cores of the rank's GPU's NUMA node (PCI address from the KFD topology) that this
+    process may run on, divided among the ranks that share the node; an even split of the allowed cores when the
+    topology does not say.  SURVEY 8(e): every GPU's launch loop gets host threads of its own, next to its GPU."""
+    allowed = sorted(os.sched_getaffinity(0))
+    even = [allowed[r * len(allowed) // world:(r + 1) * len(allowed) // world] or allowed for r in range(world)]
+    nodes = _kfd_gpu_nodes()
+    if not nodes or len(nodes) < world or any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")):
+        return even
+    local = []
+    for props in nodes[:world]:
+        try:
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7}"
+            cpus = [c for c in _cpulist(open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read()) if c in set(allowed)]
+        except (OSError, KeyError, ValueError):
+            cpus = []
+        local.append(tuple(cpus))
+    if any(not c for c in local):
+        return even
+    sets = []
+    for r in range(world):
+        peers = [q for q in range(world) if local[q] == local[r]]  # ranks whose GPUs hang off the same NUMA node
+        k, n = peers.index(r), len(peers)
+        cpus = list(local[r])
+        sets.append(cpus[k * len(cpus) // n:(k + 1) * len(cpus) // n] or cpus)
+    return sets
+
+
+def bind_rank_cpus(local_rank: int, local_world: int):
+    """Pin this rank to its CPU set (MAPF_RANK_CPUS from the parent launcher, else computed here: under torchrun the
+    ranks are somebody else's children).  Returns the set, or None when the platform has no affinity call."""
+    try:
+        spec = os.environ.get("MAPF_RANK_CPUS")
+        cpus = _cpulist(spec) if spec else rank_cpu_sets(local_world)[local_rank]
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except (AttributeError, OSError, IndexError, ValueError):
+        return None
+
+
+def launch_ranks(args, worker_argv=None) -> int:
     """Start args.gpus worker processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torchrun
-    would export) and relay rank 0's JSON line.  Runs before anything in this process touches a GPU."""
+    would export, plus the rank's CPU set) and relay rank 0's JSON line.  Nothing in this process touches a GPU, before
+    or after: the devices are counted from sysfs.  worker_argv: the command of one rank (default: this script with this
+    command line); the CPU tests pass a gloo stand-in."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     if not args.share_gpu:
-        import torch  # (counting devices does not initialise the GPU)
-
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < args.gpus:
             print(f"[bench] --gpus {args.gpus} but this node exposes {have} GPU(s)", file=sys.stderr)
             return 1
+    cpu_sets = rank_cpu_sets(args.gpus)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
-                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "MAPF_RANK_CPUS": ",".join(str(c) for c in cpu_sets[r])})
+        procs.append(subprocess.Popen(worker_argv or [sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that dies early (bad device, OOM) would leave the others waiting in the rendezvous for ever: watch all of
     # them, and when one fails stop the rest (by pid) and fail
@@ -223,7 +315,11 @@ def worker(args) -> int:
     rank, local_rank, world = sharding.dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if args.share_gpu else local_rank
+    rank_cpus = bind_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or (not args.share_gpu and local_rank >= n_dev):  # fail fast: the launcher stops the other ranks
+        raise SystemExit(f"[bench] rank {rank}: no GPU for local rank {local_rank} ({n_dev} visible)")
+    dev_index = local_rank % n_dev if args.share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun always go through RCCL, also at world size 1
@@ -337,11 +433,14 @@ def worker(args) -> int:
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         env.poll_error()
         resets = int(env.episode_sums()[L.ACC_EPISODES]) - ep0
+        per_rank = [elapsed]
         if use_dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=None if args.share_gpu else device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "resets": resets}
+            tt = torch.zeros(world, dtype=torch.float64, device=None if args.share_gpu else device)
+            tt[rank] = elapsed
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)  # (every rank's own time; the job's time is their maximum)
+            per_rank = [float(x) for x in tt.tolist()]
+            elapsed = max(per_rank)
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "resets": resets, "per_rank": per_rank}
 
     legs = {}
     if args.episodes in ("staggered", "both"):
@@ -408,6 +507,7 @@ def worker(args) -> int:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of this kernel, committed; not measured in this run)" if traffic else None,
             "kernel": "k_step", "kernel_ms": head["kernel_ms"], "isolated_launch_ms": isolated_launch_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
@@ -421,6 +521,9 @@ def worker(args) -> int:
         result["resets_in_timed_region_synchronised"] = s["resets"]
         result["roofline"]["kernel_ms_synchronised"] = s["kernel_ms"]
         result["roofline"]["frac_synchronised"] = bytes_per_launch / (s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if world > 1:
+        result["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in head["per_rank"]]
+        result["config"]["rank0_cpus"] = len(rank_cpus) if rank_cpus else None
     if args.share_gpu:
         result["shared_gpu"] = True
     if rank == 0:

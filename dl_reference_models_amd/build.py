@@ -71,5 +71,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return SO_PATH
 
 
+# The checking build (mapf_kernels.inl: MAPF_CHK): same sources with -DMAPF_CHECK, reduced to the shapes the soak of the
+# specialised kernels uses (groups of 4 and 8 lanes, 5 x 5 windows), so that it compiles in about a minute.  Selected
+# per handle with MAPF_CHECK_BUILD=1 (_lib.load); tests/test_soak_gpu.py runs one soak on it.
+CHECK_SO_PATH = os.path.join(CSRC, "libmapfstep_check.so")
+CHECK_FLAGS = ["-DMAPF_CHECK", "-DMAPF_SMALL_SHAPES"]
+
+
+def build_check(force: bool = False, verbose: bool = False) -> str:
+    stamp = CHECK_SO_PATH + ".srchash"
+    digest = source_digest() + "+check"
+    if not force and os.path.exists(CHECK_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return CHECK_SO_PATH
+    cmd = [find_hipcc(), *HIPCC_FLAGS, *CHECK_FLAGS, "-I", os.path.join(ROOT, "include"), "-o", CHECK_SO_PATH, *SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
+    return CHECK_SO_PATH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_check(force="--force" in sys.argv, verbose=True))

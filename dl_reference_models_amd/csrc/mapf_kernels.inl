@@ -29,9 +29,6 @@
 #ifndef MAPF_NS
 #define MAPF_NS
 #endif
-#ifndef MAPF_ABL
-#define MAPF_ABL 0  // development ablations of k_step3 (never in a shipped build)
-#endif
 namespace MAPF_NS {
 
 // ------------------------------------------------------------------------------------------------
@@ -807,6 +804,12 @@ __device__ __forceinline__ void load_rows_to_lds(const uint64_t *grid_rows, int 
     rows_commit<LPE>(grid_rows, H, lrows, lane, env0, ngroups, rr);
 }
 
+// per-env step mask of mapf_step_masked: an env whose byte is zero is not touched at all (state, generator, counters,
+// statistics, outputs, error latch); its lane group behaves like the idle groups of a ragged last wave
+__device__ __forceinline__ bool env_live(const Io &io, int env) {
+    return io.env_mask == nullptr || io.env_mask[min(env, io.B - 1)] != 0;
+}
+
 __device__ __forceinline__ void raise_error(const Params &p, int code, int env, int agent, int value) {
     if (atomicCAS(&p.err[0], 0, code) == 0) {
         p.err[1] = env;
@@ -814,6 +817,23 @@ __device__ __forceinline__ void raise_error(const Params &p, int code, int env, 
         p.err[3] = value;
     }
 }
+
+// Checking build (-DMAPF_CHECK; dl_reference_models_amd/build.py: build_check(), selected with MAPF_CHECK_BUILD=1): every
+// scatter / gather index into the LDS regions that the draw, the inline reset, the cell map and the staging rows compute
+// from DATA is range-checked against the region of its lane group; a violation latches MAPF_ERR_INTERNAL with the env,
+// the site id below and the offending value (mapf_poll_error).  Round 2's one real kernel bug (draw_shuffle16 storing for
+// lane groups that were not drawing, out[inv[..]] landing in a neighbour group's scratch) only showed as a wrong goal
+// cell 200 soak cases later; this build reports it at the store.  Sites: 1 raw outputs, 2 bounded draws, 3 shuffle
+// scatter (16 values), 4 shuffle scatter (128 values), 5 sequential Floyd hash / output, 6 free-cell gather index,
+// 7 cell-map index, 8 staging row, 9 slice staging, 10 scratch layout.
+#ifdef MAPF_CHECK
+#define MAPF_CHK(P, cond, site, env, val)                                                   \
+    do {                                                                                    \
+        if (!(cond)) raise_error((P), MAPF_ERR_INTERNAL, (env), (site), (int)(val));        \
+    } while (0)
+#else
+#define MAPF_CHK(P, cond, site, env, val) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // move phase (MA-env:502-526): agents move in index order against live occupancy.  Restated as a
@@ -1156,13 +1176,10 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
 // the same tensor, otherwise one contiguous run per group.
 // Observation stream stores.  The 8.6 MB of observations a launch writes are not re-read by this engine, so
 // they are pushed towards HBM while the kernel runs (write-through) instead of sitting dirty in L2 until the
-// end-of-kernel write-back (measured: DESIGN.md section 5).  MAPF_OBS_STORE: 0 = plain, 1 = nontemporal,
-// 2 = sc1 write-through.  The sc1 form is a buffer store with the cache-policy bit (aux 16), a store hipcc
-// can see: an inline-asm store reads its data registers asynchronously and the hazard recognizer does not
-// protect them (that variant corrupted 16 floats per wave in the L = 28 specialisation).
-#ifndef MAPF_OBS_STORE
-#define MAPF_OBS_STORE 2
-#endif
+// end-of-kernel write-back (measured against plain and nontemporal stores: DESIGN.md section 5).  The sc1 form is a
+// buffer store with the cache-policy bit (aux 16), a store hipcc can see: an inline-asm store reads its data registers
+// asynchronously and the hazard recognizer does not protect them (that variant corrupted 16 floats per wave in the
+// L = 28 specialisation).
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 struct ObsSink {
     __amdgpu_buffer_rsrc_t rsrc;
@@ -1176,18 +1193,8 @@ __device__ __forceinline__ ObsSink make_obs_sink(float *base, unsigned bytes) {
 }
 // store 16 bytes at byte offset `off` of the sink
 __device__ __forceinline__ void store_obs4(const ObsSink &s, unsigned off, const float4 v) {
-#if MAPF_OBS_STORE == 2
     const v4u_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(w, s.rsrc, (int)off, 0, 16);  // aux 16 = sc1
-#elif MAPF_OBS_STORE == 1
-    float *d = reinterpret_cast<float *>(reinterpret_cast<char *>(s.base) + off);
-    __builtin_nontemporal_store(v.x, d);
-    __builtin_nontemporal_store(v.y, d + 1);
-    __builtin_nontemporal_store(v.z, d + 2);
-    __builtin_nontemporal_store(v.w, d + 3);
-#else
-    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(s.base) + off) = v;
-#endif
 }
 
 // full wave, one destination, compile-time shape: straight-line 16-byte copies
@@ -1374,6 +1381,7 @@ __device__ __forceinline__ bool draw_stage_a(const Params &p, int16_t *scr, int 
             st = add128(mul128(stride_a, st), stride_c);
         }
         const uint64_t o = pcg_output(st);
+        MAPF_CHK(p, has + 2 * (q - 1) + 1 < 4 * N + 2, 1, env, has + 2 * (q - 1) + 1);
         raw[has + 2 * (q - 1)] = (uint32_t)o;
         raw[has + 2 * (q - 1) + 1] = (uint32_t)(o >> 32);
         if (raw_dst && do_reset) {
@@ -1412,6 +1420,7 @@ __device__ __forceinline__ bool draw_stage_a(const Params &p, int16_t *scr, int 
         const uint32_t excl = rng + 1u;
         const uint64_t m = (uint64_t)raw[k] * excl;
         rej |= (uint32_t)m < excl;
+        MAPF_CHK(p, k < 4 * N, 2, env, k);
         vals[k] = (uint16_t)(m >> 32);
     }
     ok = ok && gballot<LPE>(rej, lane) == 0;
@@ -1461,8 +1470,9 @@ __device__ __forceinline__ void draw_floyd16(int16_t *scr, int lane, int a, int 
 // _shuffle_int tail shuffle with the precomputed indices vals[2N ..): the permutation fits one 64-bit register as
 // nibbles; every lane applies the swaps to it and then places its chosen values in out[] (group scratch).
 template <int LPE>
-__device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, int N, int c0, int c1, bool on) {
-    (void)lane;
+__device__ __forceinline__ void draw_shuffle16(const Params &p, int env, int16_t *scr, int lane, int a, int N, int c0, int c1,
+                                               bool on) {
+    (void)lane; (void)p; (void)env;
     // `on`: groups that are not drawing run along on whatever their scratch holds; their swap indices are junk, the
     // nibbles no bijection and inv[] partly unwritten, so they must not store (out[inv[..]] would land in another
     // group's scratch)
@@ -1488,13 +1498,20 @@ __device__ __forceinline__ void draw_shuffle16(int16_t *scr, int lane, int a, in
     if (on)
         for (int x = a; x < 16; x += LPE) inv[(perm >> (4 * x)) & 15ull] = (uint8_t)x;  // all 16 nibbles: a bijection
     wave_lds_sync();
-    if (on && a < size) out[inv[a] & 15] = (int16_t)c0;
-    if (on && a + LPE < size) out[inv[a + LPE] & 15] = (int16_t)c1;
+    if (on && a < size) {
+        MAPF_CHK(p, (inv[a] & 15) < size, 3, env, inv[a]);
+        out[inv[a] & 15] = (int16_t)c0;
+    }
+    if (on && a + LPE < size) {
+        MAPF_CHK(p, (inv[a + LPE] & 15) < size, 3, env, inv[a + LPE]);
+        out[inv[a + LPE] & 15] = (int16_t)c1;
+    }
 }
 
 // Second half: Floyd's sampling and the tail shuffle on vals[] (group scratch) -> out[2N] (group scratch).
 template <int LPE>
-__device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool ok, int N, int pop) {
+__device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *scr, int lane, int a, bool ok, int N, int pop) {
+    (void)p; (void)env;
     const int size = 2 * N;
     uint32_t *raw = reinterpret_cast<uint32_t *>(scr);
     uint16_t *vals = reinterpret_cast<uint16_t *>(raw + 4 * N + 2);
@@ -1503,7 +1520,7 @@ __device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool
     int c0 = -1, c1 = -1;
     if (size <= 16) {
         draw_floyd16<LPE>(scr, lane, a, N, pop, c0, c1);
-        draw_shuffle16<LPE>(scr, lane, a, N, c0, c1, ok);
+        draw_shuffle16<LPE>(p, env, scr, lane, a, N, c0, c1, ok);
     } else {
         // Longer lists (N > 8: up to 128 values at N = 64).  Floyd's sampling and the tail shuffle are sequential as
         // NumPy writes them, 2N dependent iterations each (40 k cycles of one wave at N = 64, during which the other
@@ -1554,6 +1571,8 @@ __device__ __forceinline__ void draw_stage_b(int16_t *scr, int lane, int a, bool
                 p0 = n0;
                 p1 = n1;
             }
+            MAPF_CHK(p, !(ok && a < size) || (unsigned)p0 < (unsigned)size, 4, env, p0);
+            MAPF_CHK(p, !(ok && a + LPE < size) || (unsigned)p1 < (unsigned)size, 4, env, p1);
             if (ok && a < size) out[p0 & (2 * LPE - 1)] = (int16_t)c0;
             if (ok && a + LPE < size) out[p1 & (2 * LPE - 1)] = (int16_t)c1;
         } else {
@@ -1588,7 +1607,7 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
                                                              bool env_ok, bool do_reset, int N, const uint64_t *rng_src) {
     int pop = 0;
     const bool ok = draw_stage_a<LPE>(p, scr, lane, a, env, env_ok, do_reset, N, nullptr, PcgPre{false, {}, 0, {}, {}}, rng_src, pop);
-    draw_stage_b<LPE>(scr, lane, a, ok, N, pop);
+    draw_stage_b<LPE>(p, env, scr, lane, a, ok, N, pop);
     return ok;
 }
 
@@ -1626,6 +1645,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
             const uint64_t *rng_src = staged ? p.vis_rng : p.rng;
             int16_t *hs = scratch + grp * p.scratch_i16;
             const int16_t *out = hs + sample_out_off_i16(N);
+            MAPF_CHK(p, sample_out_off_i16(N) + 2 * N + 8 <= p.scratch_i16 && p.hash_cap + 2 * N <= p.scratch_i16, 10, env, p.scratch_i16);
             const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, rng_src);
             MAPF_STAMP_RG(25);
             if (__any(draw && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
@@ -1642,6 +1662,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
                         // the set holds at most 2N < hash_cap entries, so an empty slot always exists; the
                         // probe counters only make termination structural
                         for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                        MAPF_CHK(p, (unsigned)loc < (unsigned)hash_cap && (unsigned)(j - pop + size) < (unsigned)size, 5, env, loc);
                         if (hs[loc] == -1) {
                             hs[loc] = (int16_t)val;
                             outs[j - pop + size] = (int16_t)val;
@@ -1667,6 +1688,7 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
             if (draw && is_agent) {
                 const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
                 const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+                MAPF_CHK(p, (unsigned)out[a] < (unsigned)p.n_free[env] && (unsigned)out[N + a] < (unsigned)p.n_free[env], 6, env, out[a]);
                 st.start = fc[min(max((int)out[a], 0), top)];
                 st.goal = fc[min(max((int)out[N + a], 0), top)];
             }
@@ -1728,7 +1750,7 @@ struct Lds {
     uint4 *tab;
     uint4 *otab;  // two-wave step kernels: the entries the observation wave reads (x old|new<<16, y goal, w kObsW*);
                   // two copies, used alternately by consecutive steps of the fused kernel (carve_lds + set_parity)
-    uint4 *xpose;  // 3 KiB: the wave's 64 agent records on their way out (store_lanes_coalesced)
+    uint4 *xpose;  // 3 KiB of staging: info rows and counters of the wave's envs on their way out (step_body)
     float *stage;
     int16_t *scratch;
     uint32_t *map;  // [G][H + 2*kRowPad][W + 2*kRowPad] cell words (only when Io::use_map)
@@ -1825,11 +1847,8 @@ __global__ __launch_bounds__(64) void k_observe(const Params *__restrict__ pp, c
 // state image while the other wave builds, stages and streams out the observations.  With one wave per SIMD
 // (c3: 1024 workgroups on 1024 SIMDs) a step is bound by one wave's dependent-instruction latency, not by
 // bandwidth or issue slots; the split takes the observation (about a third of the instructions) off that path.
-// A/B: 1 = the post-B1 episode-end blocks of the state wave (record image, end-of-body) are laid out inline (the image
-// selects run in every wave) instead of as cold code
-#ifndef MAPF_INLINE_RESET_TAIL
-#define MAPF_INLINE_RESET_TAIL 0
-#endif
+// (The post-B1 episode-end blocks of the state wave -- record image, end of body -- are cold code: laid out inline their
+// selects ran in every wave)
 constexpr uint32_t kObsWAgent = 1u, kObsWPressure = 2u, kObsWFinal = 4u, kObsWSelShift = 3u, kObsWFast = 32u,
                    kObsWReset = 64u,       // the state wave builds this group's reset observation itself, after B2
                    kObsWResetFast = 128u;  // the observation wave builds it (second pass) from entry word z
@@ -1843,7 +1862,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                                           const bool store_inside = false, const bool nsg_lazy = false) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
-    const bool env_ok = FAST ? true : (grp < ngroups);
+    const bool env_ok = FAST ? true : (grp < ngroups && env_live(io, env0 + grp));
     const int env = env_ok ? env0 + grp : io.B - 1;
     const int N = K::N(p), H = io.H, W = io.W;
     const uint32_t flags = K::flags(p);
@@ -1908,6 +1927,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     const int map_w = W + 2 * kRowPad;
     uint32_t *mapg = l.map + grp * (H + 2 * kRowPad) * map_w;
     if (use_map) {
+        MAPF_CHK(p, !is_agent || (unsigned)map_index(old, map_w) < (unsigned)((H + 2 * kRowPad) * map_w), 7, env, old);
         if (is_agent) atomicOr(&mapg[map_index(old, map_w)], ((uint32_t)a + 1u) << 7);  // owner-old field
         if (__any(want)) cur = resolve_moves_map<K, LPE>(p, mapg, map_w, lane, a, old, tgt);
         else wave_lds_sync();
@@ -1971,9 +1991,6 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
             nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
         bool slot_ok = deterministic;
         if (!deterministic && !lifelong) slot_ok = gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
-#ifdef MAPF_NO_FAST_RESET  // (A/B builds)
-        slot_ok = false;
-#endif
         fast_reset = do_reset && !use_map && slot_ok && (obs_wave || !want_any_obs);
         slow_reset = do_reset && !fast_reset;
         subst = fast_reset && io.final_obs == nullptr;  // reset observation in place of the terminal one
@@ -2148,6 +2165,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     // neighbour / blocking pass
     PairOut po;
     float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
+    MAPF_CHK(p, !is_agent || (grp * N + a + 1) * K::L(p) * 4 <= io.lds_scratch_off - io.lds_stage_off, 8, env, grp * N + a);
     // this wave builds the observation itself unless the other wave does, or nobody asked for one (fused steps
     // without observations)
     const bool emit_here = !obs_wave && (io.obs || io.final_obs);
@@ -2160,6 +2178,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         // then reads only its window and lock neighbourhood from it (single-wave workgroups only: dual_for())
         if (is_agent) {
             const uint32_t me1 = (uint32_t)a + 1u;
+            MAPF_CHK(p, (unsigned)map_index(cur, map_w) < (unsigned)((H + 2 * kRowPad) * map_w) &&
+                            (unsigned)map_index(st.goal, map_w) < (unsigned)((H + 2 * kRowPad) * map_w) &&
+                            (unsigned)((tr + kRowPad) * map_w + tc + kRowPad) < (unsigned)((H + 2 * kRowPad) * map_w), 7, env, cur);
             atomicOr(&mapg[map_index(cur, map_w)], me1 | ((uint32_t)(delta + 256) << 22));
             atomicOr(&mapg[map_index(st.goal, map_w)], me1 << 14);
             // intended_next may lie one cell outside the grid: that is inside the map's border
@@ -2233,7 +2254,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         st.pos = cur;
         st.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
         Lane img = st;
-        if (MAPF_INLINE_RESET_TAIL || __builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+        if (__builtin_expect(__any(fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
             const uint32_t rs = reset_placement();
             img.start = fast_reset ? (rs & 0xFFFFu) : st.start;
             img.goal = fast_reset ? (rs >> 16) : st.goal;
@@ -2371,7 +2392,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
 
     // ---- auto-reset of finished envs (reference harness loop scripts/benchmark_multi_agent_env.py:89-95:
     //      reset() right after a done step) ------------------------------------------------------------
-    if (MAPF_INLINE_RESET_TAIL ? __any(fast_reset) : __builtin_expect(__any(fast_reset), 0)) {  // placement known: reset() is a register image (MA-env:440-455), the observation wave
+    if (__builtin_expect(__any(fast_reset), 0)) {  // placement known: reset() is a register image (MA-env:440-455), the observation wave
                               // has (or is building) the reset observation
         if (fast_reset) {
             const uint32_t rs = reset_placement();
@@ -2588,6 +2609,7 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
     if (__any(stage == 3)) {  // ---- bounded draws (Lemire) on the raw outputs
         const bool on = stage == 3;
         if (on) {
+            MAPF_CHK(p, (hs - scratch) + 2 * (4 * N + 2) <= (long)(64 / LPE) * p.scratch_i16, 9, env, grp);
 #pragma unroll
             for (int i = 0; i < 5; i++)
                 if (a + i * LPE < 4 * N + 2) raw[a + i * LPE] = d.sv[i];
@@ -2638,7 +2660,7 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         }
         wave_lds_sync();
         const int c0 = (int)vals[a], c1 = (int)vals[a + LPE];
-        draw_shuffle16<LPE>(hs, lane, a, N, c0, c1, on);
+        draw_shuffle16<LPE>(p, env, hs, lane, a, N, c0, c1, on);
         wave_lds_sync();
         if (on) {
             sv[a] = out32[a];  // N dwords = idx[2N]
@@ -2766,7 +2788,7 @@ __device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, unsi
                 for (int k = a; k < 2 * N; k += LPE) vals32[k] = stage[k];
             }
             wave_lds_sync();
-            draw_stage_b<LPE>(hs, lane, a, act_b, N, pop);
+            draw_stage_b<LPE>(p, env, hs, lane, a, act_b, N, pop);
             if (act_b && a < N) {
                 const int16_t *out = hs + sample_out_off_i16(N);
                 const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
@@ -2785,15 +2807,12 @@ __device__ __forceinline__ void sampler_wave(const Params &p, const Io &io, unsi
 }
 
 // Workgroup shape of the step kernels: kStepWaves waves of 64 lanes.  Wave 0 is the state wave, wave 1 (when
-// present) the observation wave.  MAPF_DUAL=0 builds the single-wave variant (A/B measurements).
-#ifndef MAPF_DUAL
-#define MAPF_DUAL 1
-#endif
+// present) the observation wave.
 // k_step uses the split for every group width (c5, N = 64 with the LDS cell map: 10.2 -> 8.8 us).  The fused
 // kernel keeps wide groups single-wave: its cell map is single-buffered, so the waves would have to meet at the
 // end of every step, and the loop body then spills several hundred SGPRs (measured: 5.9 -> 8.8 us per step).
-constexpr bool dual_for(int lpe) { return MAPF_DUAL != 0 && lpe >= 4; }
-constexpr bool dual_many_for(int lpe) { return MAPF_DUAL != 0 && lpe < 32; }
+constexpr bool dual_for(int lpe) { return lpe >= 4; }
+constexpr bool dual_many_for(int lpe) { return lpe < 32; }
 constexpr int step_threads(int lpe) { return dual_for(lpe) ? 128 : 64; }
 constexpr int many_threads(int lpe) { return dual_many_for(lpe) ? 128 : 64; }
 
@@ -2819,11 +2838,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
     constexpr int kWavesPerWg = kDual ? 2 : 1;
     const int main_blocks = (io.B + G - 1) / G;
     // leading sampler workgroups shift the env workgroups (sampler_blocks_for: a function of the preloaded B alone)
-#ifdef MAPF_NO_SAMPLER_WG  // (A/B builds: the host launches no sampler workgroups)
-    const int lead = 0;
-#else
     const int lead = K::kSamplerFront ? sampler_blocks_for(io.B, kWavesPerWg) : 0;
-#endif
     const int env0 = ((int)blockIdx.x - lead) * G;
     const int ngroups = min(G, io.B - env0);
     const int N = K::N(p);
@@ -2841,10 +2856,7 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
 
     // env workgroups issue ahead of a sampler wave that shares their SIMD (both of their waves at the same priority:
     // ranking state against observation wave was measured and is a loss)
-#ifndef MAPF_MAIN_PRIO
-#define MAPF_MAIN_PRIO 2
-#endif
-    __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
+    __builtin_amdgcn_s_setprio(2);
     // Both waves issue their global loads from the preloaded arguments alone, and only then wait for the scalar
     // loads (rest of the arguments, Params) in one batch.
     if (kDual && wv == 1) {
@@ -2869,19 +2881,10 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
         // state wave and set the launch's duration (6.2 against 5.5 us per step at c3 with staggered episodes).  Its
         // LDS is the draw scratch of its lane group, which the state wave only touches in a slow reset at the end of
         // its body -- and never for this env in this launch (MAY_FINISH hint).
-#ifndef MAPF_SLICE_EARLY
-#define MAPF_SLICE_EARLY 1  // A/B: 0 = at the tail of the observation wave
-#endif
-        auto run_slice = [&]() {
+        {
             if (K::kSlicedDraw && __builtin_expect(__any(d_stage != 0), 0)) {
                 MAPF_STAMP_W1(21);
-#ifdef MAPF_SLICE_PRIO  // (A/B) the background slice yields issue slots to the waves that are still stepping
-                __builtin_amdgcn_s_setprio(MAPF_SLICE_PRIO);
-#endif
                 draw_slice<K, LPE>(p, io, l.scratch, lane, d_env, d_stage, dreq);
-#ifdef MAPF_SLICE_PRIO
-                __builtin_amdgcn_s_setprio(MAPF_MAIN_PRIO);
-#endif
 #ifdef MAPF_STAMPS
                 MAPF_STAMP_W1(22);
                 {
@@ -2895,25 +2898,21 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
                 if (K::kSlicedDraw && p.dbg && threadIdx.x == 64) p.dbg[(size_t)(env0 / (64 / LPE)) * kDbgRow + 23] = 0;
 #endif
             }
-        };
-        if (MAPF_SLICE_EARLY) run_slice();
+        }
         if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
-        if (!MAPF_SLICE_EARLY) run_slice();
         return;
     }
 
-    const bool full = ngroups == G && N == LPE;  // wave-uniform
-    const bool env_ok = grp < ngroups;
+    bool full = ngroups == G && N == LPE;  // wave-uniform
+    bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
-    const bool is_agent = env_ok && a < N;
+    bool is_agent = env_ok && a < N;
 
     // ---- loads: agent record, action, env scalars (and the obstacle rows in the single-wave build)
-#ifndef MAPF_NSG_MODE
-#define MAPF_NSG_MODE 0  // A/B: 0 slot dword fetched with the state (after it), 1 only when an env finishes, 2 before the state
-#endif
-    constexpr int kNsgMode = WPS != 0 ? 1 : MAPF_NSG_MODE;  // (dense build: 32 B per env and launch less)
+    // the slot dword comes with the state loads; the dense build fetches it only when an env finishes (32 B per env and
+    // launch less)
+    constexpr int kNsgMode = WPS != 0 ? 1 : 0;
     uint32_t nsg = kSlotInvalid;  // pre-drawn placement of the next episode
-    if (kNsgMode == 2) nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
     LaneRaw raw;
     lane_issue(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), raw);
     int act = (int)io.actions[(size_t)env * N + min(a, N - 1)];
@@ -2926,6 +2925,11 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
     warm_scalar_cache(pp, tail);
     __builtin_amdgcn_sched_barrier(0);
     const Lds l = carve_lds(io, lds_raw);
+    if (__builtin_expect(io.env_mask != nullptr, 0)) {  // mapf_step_masked: masked-out envs are idle groups
+        env_ok = env_ok && io.env_mask[env] != 0;
+        is_agent = is_agent && env_ok;
+        full = full && __all(env_ok);
+    }
     Lane st;
     lane_unpack(raw, full || is_agent, st);
     act = (full || is_agent) ? act : 0;
@@ -3120,135 +3124,39 @@ __device__ __forceinline__ uint32_t obs_flags_for(const Io &io, const EndDecisio
 }
 
 // ---- wave 1 of k_step3 -------------------------------------------------------------------------------------------
-// The observation wave no longer idles until the moves are known.  Everything but the moves is there when its own loads
-// are: positions, goals, actions, the obstacle rows.  Before B1 it builds, per agent, the bit planes of a (V+2) x (V+2)
-// SUPERSET window centred on the cell the agent stands on (row stride 8 bits): obstacles, goals, own goal, the other
-// agents on their old cells, and for every lower-index agent j the two-bit difference D_j between "j on its old cell"
-// and "j on the cell it wants".  After B1 the state wave's verdict is one bit per agent (moved or not): the occupancy at
-// "time i" (MA-env:528: agents < i on their new cell, agents > i on their old one) is A0 xor the D_j of the movers, and
-// the agent's own move shifts the V x V window inside the superset.  An env whose episode is sure to end at the step
-// limit with a pre-drawn placement is handled the same way with the reset state as input (nobody moves): its reset
-// observation replaces the terminal one (step_body: subst).  Everything else -- an unpredicted ending (success), a slow
-// reset, a caller who wants the terminal observation -- takes the general path: the table walk of obs_wave_step.
+// The observation wave: waits for the moves (B1), decides for itself how the step ends for each of its envs
+// (decide_end), completes the entries the state wave published -- flags; for an env whose reset observation replaces the
+// terminal one: everybody on its start, the new goals (step_body: subst) -- and walks them (obs_wave_step).
+// (Tried and dropped, round 3: building the bit planes of a (V+2) x (V+2) superset window around the OLD position before
+// B1 -- obstacles, goals, the others on their old cells, per lower-index agent the two-bit difference between old and
+// wanted cell -- and only patching after B1 (xor of the movers' differences, window shifted by the agent's own move).
+// It takes the table walk off the path behind B1 but costs ~250 more vector instructions per wave than it saves, and
+// after B1 this kernel is bound by instruction issue on the SIMD, not by any wave's latency: 5.67 against 5.40 us.)
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                          const uint2 hot, const int act_real, const uint32_t nsg, const int step_count_in) {
+                                          const uint2 hot, const uint32_t nsg, const int step_count_in) {
     constexpr int G = 64 / LPE;
-    using gm_t = typename GMask<LPE>::type;
-    const int grp = lane / LPE, a = lane % LPE;
-    const int N = K::N(p), H = io.H, V = K::V(p), sr = K::sr(p), S = V + 2;
-    const uint32_t flags = K::flags(p);
-    const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
-    float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
-    const uint32_t pos_real = hot.x & 0xFFFFu, goal_real = hot.x >> 16;
+    const int N = K::N(p);
+    const uint32_t goal_real = hot.x >> 16;
     const bool pressure_real = ((hot.y >> 16) & kFlagPressure) != 0;
-#ifndef MAPF_OBS_PRE
-#define MAPF_OBS_PRE 0
-#endif
-    constexpr bool kPre = MAPF_OBS_PRE != 0 && MW == 32;  // (the superset of wider windows does not fit 8 x 8 bits)
-
-    bool pred = false;
-    uint32_t pos_in = pos_real, goal_in = goal_real, cand = pos_real;
-    int dr = 0, dc = 0;
-    uint64_t obst = 0, A0 = 0, Gs = 0, own = 0, D[LPE - 1];
-    if (kPre) {
-        const bool slot_ok = gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
-        pred = io.auto_reset && io.final_obs == nullptr && step_count_in + 1 >= io.steps_per_episode && slot_ok;
-        pos_in = pred ? (nsg & 0xFFFFu) : pos_real;
-        goal_in = pred ? (nsg >> 16) : goal_real;
-        const int act_in = pred ? 0 : act_real;
-        const int r0s = (int)(pos_in >> 8) - sr - 1, c0s = (int)(pos_in & 255u) - sr - 1;
-        if (io.col_pad) {
-#pragma unroll
-            for (int d = 0; d < 7; d++)
-                if (d < S) obst |= (uint64_t)row_window_padded(myrows[r0s + d], c0s, S, io.col_pad) << (8 * d);
-        } else {
-#pragma unroll
-            for (int d = 0; d < 7; d++)
-                if (d < S) obst |= (uint64_t)row_window_wide(myrows[r0s + d], c0s, S) << (8 * d);
-        }
-        dr = (act_in == 1) ? -1 : ((act_in == 3) ? 1 : 0);
-        dc = (act_in == 2) ? 1 : ((act_in == 4) ? -1 : 0);
-        const int ctr = 8 * (sr + 1) + (sr + 1);
-        const bool want = act_in != 0 && ((obst >> ((ctr + 8 * dr + dc) & 63)) & 1ull) == 0;
-        cand = want ? (uint32_t)(((int)pos_in + (dr << 8) + dc) & 0xFFFF) : pos_in;
-        uint32_t xo[LPE - 1], xg[LPE - 1];
-        group_xchg<LPE>(pos_in | (cand << 16), xo);
-        group_xchg<LPE>(goal_in, xg);
-        auto bit8 = [&](uint32_t cell) -> uint64_t {  // the cell's bit in my superset window, or nothing
-            const int rr = (int)((cell >> 8) & 255u) - r0s, cc = (int)(cell & 255u) - c0s;
-            const bool in = max((unsigned)rr, (unsigned)cc) < (unsigned)S;
-            return in ? (1ull << ((8 * rr + cc) & 63)) : 0ull;
-        };
-        own = bit8(goal_in);
-        Gs = own;
-#pragma unroll
-        for (int k = 1; k < LPE; k++) {
-            const uint64_t bo = bit8(xo[k - 1] & 0xFFFFu), bc = bit8(xo[k - 1] >> 16);
-            A0 ^= bo;
-            Gs |= bit8(xg[k - 1]);
-            D[k - 1] = ((a ^ k) < a) ? (bo ^ bc) : 0ull;
-        }
-    }
     wg_sync();  // B1: the moves
-    MAPF_STAMP_W1(11);
+    // After B1 the workgroup's SIMDs are issue-bound (three busy waves each).  The observation wave goes first: its
+    // stream is what the launch ends with, and the aux wave's work then fills the slots under that stream's drain.
+    __builtin_amdgcn_s_setprio(3);  // (measured, us per step staggered / synchronised: obs 3, aux 1, slice 0: 5.52 / 5.08;
+                                    //  all at 2: 5.76 / 5.31; obs 3, aux 2, slice 1: 5.87 / 5.40; obs 1, aux 3: 5.61 / 5.40)
     const uint4 ent = l.otab[lane];
     const uint32_t cur = ent.y >> 16;
     const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal_real, step_count_in + 1, nsg);
-    const bool special = dec.slow_reset || (dec.fast_reset && !dec.subst) || (dec.subst != pred);
-    if (!kPre || io.obs == nullptr || __builtin_expect(__any(special), 0)) {
-        // ---- general path: complete the entries (flags; a substituted env: everybody on its start, the new goals) and
-        //      walk them (obs_wave_step); word y's upper half (the real new cell) is the aux wave's and stays
-        const uint32_t w = obs_flags_for(io, dec, pressure_real);
+    const uint32_t w = obs_flags_for(io, dec, pressure_real);
+    uint4 mine = make_uint4(ent.x, ent.y, 0u, w);  // (word y's upper half, the real new cell, is the aux wave's and stays)
+    if (__builtin_expect(__any(dec.fast_reset), 0)) {
         const uint32_t rs = nsg, rs_pos = rs & 0xFFFFu;
-        uint4 mine = make_uint4(ent.x, ent.y, dec.fast_reset ? rs : 0u, w);
+        if (dec.fast_reset) mine.z = rs;
         if (dec.subst) mine = make_uint4(rs_pos | (rs_pos << 16), (rs >> 16) | (cur << 16), rs, w);
-        l.otab[lane] = mine;
-        wave_lds_sync();
-        obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true);
-        return;
     }
-#if MAPF_ABL == 1  // (ablation: the observation wave stops at B1)
-    return;
-#endif
-    // ---- fast path ----
-    const gm_t M = pred ? (gm_t)0 : gballot_n<LPE>(cur != pos_real, lane);
-    uint64_t A = A0;
-#pragma unroll
-    for (int k = 1; k < LPE; k++) A ^= ((M >> (a ^ k)) & 1u) ? D[k - 1] : 0ull;
-    const bool mv = ((M >> a) & 1u) != 0;
-    const int sh = 8 * (1 + (mv ? dr : 0)) + 1 + (mv ? dc : 0);
-    const uint32_t new_pos = mv ? cand : pos_in;
-    const uint64_t oa = obst | A;
-    const uint64_t g3 = own & ~oa;
-    const uint64_t g4 = Gs & ~(oa | own);
-    const uint64_t b0 = obst | g3;
-    const uint64_t b1 = (A & ~obst) | g3;
-    auto compact = [&](uint64_t x) -> WMask<32> {  // V x V window at offset sh of the superset -> row stride V
-        x >>= sh;
-        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32), m = (1u << V) - 1u;
-        uint32_t c = lo & m;
-        if (V > 1) c |= ((lo >> 8) & m) << V;
-        if (V > 2) c |= ((lo >> 16) & m) << (2 * V);
-        if (V > 3) c |= ((lo >> 24) & m) << (3 * V);
-        if (V > 4) c |= (hi & m) << (4 * V);
-        return WMask<32>{c};
-    };
-    const bool norm = (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
-    emit_obs_planes<K, 32, 5>(p, srow, compact(b0), compact(b1), compact(g4), compact(oa),
-                              goal_delta((int)((goal_in >> 8) & 255u) - (int)(new_pos >> 8), io.den_r, norm),
-                              goal_delta((int)(goal_in & 255u) - (int)(new_pos & 255u), io.den_c, norm), !pred && pressure_real);
+    l.otab[lane] = mine;
     wave_lds_sync();
-    MAPF_STAMP_W1(12);
-#if MAPF_ABL == 4  // (ablation: no observation stream)
-    return;
-#endif
-    flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
-    MAPF_STAMP_W1(13);
-#ifdef MAPF_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MAPF_STAMP_W1(14);
-#endif
+    obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true);
 }
 
 // ---- wave 2 of k_step3 -------------------------------------------------------------------------------------------
@@ -3272,10 +3180,8 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
 
     MAPF_STAMP_W2(21);
     wg_sync();  // B1: the moves are published
+    __builtin_amdgcn_s_setprio(1);  // (behind the observation wave: obs3_wave)
     MAPF_STAMP_W2(22);
-#if MAPF_ABL == 2  // (ablation: the aux wave stops at B1)
-    return;
-#endif
     const uint32_t cur = l.otab[lane].y >> 16;  // (the rest of the entry is the observation wave's)
     sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
     const EndDecision dec = decide_end<LPE>(io, N, lane, cur, st.goal, sc[MAPF_CTR_STEP_COUNT], nsg);
@@ -3406,7 +3312,7 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
         const int goals_total = reached_cnt;
         const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
         float2 *xi = reinterpret_cast<float2 *>(aux_lds);
-        uint4 *xs = reinterpret_cast<uint4 *>(aux_lds + 512);
+        uint4 *xs = reinterpret_cast<uint4 *>(aux_lds + 1024);  // (info: 16 groups x 56 bytes at most)
         if (a == 0) {
             float2 *q = xi + grp * 7;
             q[0] = make_float2((float)goals_step, (float)goals_total);
@@ -3487,9 +3393,6 @@ __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const
     l.otab[lane] = make_uint4(old | (cur << 16), goal | (cur << 16), nsg, 0u);
     wg_sync();  // B1
     MAPF_STAMP(19);
-#if MAPF_ABL == 3  // (ablation: the state wave stops at B1)
-    return;
-#endif
     // ---- an env of the wave ends its episode without a pre-drawn placement (rare): draw inline (reset_groups, B2 inside)
     const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal, step_count_in + 1, nsg);
     if (__builtin_expect(__any(dec.slow_reset), 0)) {
@@ -3531,7 +3434,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const size_t idx = (size_t)env * N + a;
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(2);  // (until B1; afterwards: observation wave 3, aux wave 1, background slice 0)
 
     // every wave reads the actions: FAST (full workgroup, no invalid action) is decided by each of them from the same bytes
     if (wv == 1) {
@@ -3549,13 +3452,13 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         wave_lds_sync();
         MAPF_STAMP_W1(10);
         act1 = env_ok ? act1 : 0;
-        const bool fast3 = full && !__any(act1 < 0 || act1 > 4);
+        const bool fast3 = full && io.env_mask == nullptr && !__any(act1 < 0 || act1 > 4);
         if (__builtin_expect(!fast3, 0)) {  // the two-wave code
             wg_sync();  // B0
             if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
             return;
         }
-        if (io.obs || io.final_obs) obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, act1, nsg1, step1);
+        if (io.obs || io.final_obs) obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1);
         else wg_sync();  // B1 (the other waves read the rows behind it)
         return;
     }
@@ -3584,8 +3487,8 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
     warm_scalar_cache(pp, tail);
     __builtin_amdgcn_sched_barrier(0);
     const Lds l = carve_lds(io, lds_raw);
-    unsigned char *aux_lds = lds_raw + io.lds_map_off;  // (k_step3: 1 KiB for the aux wave's info / counter staging)
-    const bool is_agent = env_ok;  // (N == LPE)
+    unsigned char *aux_lds = lds_raw + io.lds_map_off;  // (k_step3: 2 KiB for the aux wave's info / counter staging)
+    bool is_agent = env_ok;  // (N == LPE)
     act = (full || is_agent) ? act : 0;
 #ifdef MAPF_STAMPS
     if (wv == 0) {
@@ -3593,10 +3496,12 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         MAPF_STAMP(0);
     }
 #endif
-    const bool fast3 = full && !__any(act < 0 || act > 4);
+    const bool fast3 = full && io.env_mask == nullptr && !__any(act < 0 || act > 4);
     if (__builtin_expect(!fast3, 0)) {
-        // ---- a ragged last workgroup or an invalid action: the two-wave code of k_step ----
+        // ---- a ragged last workgroup, an invalid action or a masked step: the two-wave code of k_step ----
         if (wv == 2) return;  // before any barrier
+        is_agent = is_agent && env_live(io, env);
+        act = is_agent ? act : 0;
         lane_issue_hist(io.agents, io.bn8, idx, raw);
         load_scal(io.scal, env, sc);
         Lane st;
@@ -3605,7 +3510,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         step_body<K, LPE, MW, false, true>(p, io, l, lane, env0, ngroups, act, st, sc, nsg, false, false);
         if (is_agent)
             store_lane(io.agents, io.bn8, idx, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
-        if (env_ok && a == 0) store_scal(io.scal, env, sc);
+        if (is_agent && a == 0) store_scal(io.scal, env, sc);
         return;
     }
     if (wv == 0) {
@@ -3618,6 +3523,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
             dreq.w0 = group_bcast<0, LPE>(nsg);
             const int d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
             if (__builtin_expect(__any(d_stage != 0), 0)) {
+                __builtin_amdgcn_s_setprio(0);  // (background work: behind everything that a step waits for)
                 MAPF_STAMP(4);
                 draw_slice<K, LPE>(p, io, l.scratch, lane, env, d_stage, dreq);
 #ifdef MAPF_STAMPS
@@ -4138,8 +4044,14 @@ constexpr uint32_t kFlagsHeadline = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_A
                                     MAPF_FLAG_BLOCKING_PRESSURE | MAPF_FLAG_LOCK_METRICS;  // L = 33
 constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_BLOCKING_PRESSURE |
                                       MAPF_FLAG_LOCK_METRICS;  // the reference's default obs, L = 28
-#ifdef MAPF_DEV_C3  // development builds (mapf_step.hip): the headline shape only
+#if defined(MAPF_DEV_C3)  // development builds (mapf_step.hip): the headline shape only
 #define MAPF_SPECIALIZATIONS(X) X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)
+#elif defined(MAPF_SMALL_SHAPES)  // the checking build
+#define MAPF_SPECIALIZATIONS(X)                 \
+    X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)   \
+    X(2, 4, 2, kFlagsHeadline, 8, 16, 2, 1, 4)   \
+    X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8) \
+    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)
 #else
 #define MAPF_SPECIALIZATIONS(X)                                            \
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)                              \

@@ -36,6 +36,8 @@
 #include <fstream>
 #include <type_traits>
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -49,8 +51,11 @@
 // Group widths and window-mask widths the dispatchers below instantiate.  -DMAPF_DEV_C3 (development builds only: the
 // library is then good for the c3 shape and nothing else) cuts them to what the headline shape needs, so that an edit of
 // the step kernel can be compiled in under a minute instead of several.
-#ifdef MAPF_DEV_C3
+#if defined(MAPF_DEV_C3)
 #define MAPF_FOR_LPE(X) X(8)
+#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
+#elif defined(MAPF_SMALL_SHAPES)  // (the checking build: groups of 4 and 8 lanes, windows up to 5 x 5)
+#define MAPF_FOR_LPE(X) X(4) X(8)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
 #else
 #define MAPF_FOR_LPE(X) X(4) X(8) X(16) X(32) X(64)
@@ -295,6 +300,7 @@ struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t step = nullptr, many = nullptr;
     double seconds = 0;
+    bool from_disk = false;
 };
 std::mutex g_jit_mutex;
 std::map<std::string, JitModule> g_jit_cache;  // key: device + the instantiation
@@ -308,6 +314,30 @@ std::string library_dir() {
     return k == std::string::npos ? "." : f.substr(0, k);
 }
 
+// On-disk cache of compiled code objects: MAPF_JIT_CACHE_DIR, else $XDG_CACHE_HOME/mapf_jit, else ~/.cache/mapf_jit (empty
+// MAPF_JIT_CACHE_DIR = no cache).  A file is named by a hash of everything the code object depends on -- the kernel
+// source and the ABI header as found next to the library, the instantiations, the target and the compile options -- so
+// a rebuilt library or an edited source never meets a stale entry; the 0.5-2.5 s of hiprtc are paid once per machine and
+// configuration instead of once per process.
+static std::string jit_cache_dir() {
+    if (const char *d = getenv("MAPF_JIT_CACHE_DIR")) return d;
+    if (const char *x = getenv("XDG_CACHE_HOME")) if (*x) return std::string(x) + "/mapf_jit";
+    if (const char *h = getenv("HOME")) if (*h) return std::string(h) + "/.cache/mapf_jit";
+    return "";
+}
+static uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+static std::string slurp(const std::string &path) {
+    std::ifstream f(path, std::ios::binary);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+static void mkdirs(const std::string &dir) {  // best effort (like `mkdir -p`)
+    for (size_t k = 1; k <= dir.size(); k++)
+        if (k == dir.size() || dir[k] == '/') (void)mkdir(dir.substr(0, k).c_str(), 0777);
+}
+
 // Tries to give `e` step kernels compiled for its configuration; on any failure e->jit_note says why.
 void jit_specialize(mapf_engine *e) {
     const mapf_config &c = e->cfg;
@@ -319,6 +349,7 @@ void jit_specialize(mapf_engine *e) {
     if (e->special && !getenv("MAPF_JIT_PREBUILT_TOO")) { e->jit_note = "a prebuilt specialisation matches"; return; }
     if (lpe != pick_lpe(N)) { e->jit_note = "lanes_per_env overrides the group width"; return; }
     if (N > 16 && !e->use_map) { e->jit_note = "wide group without the LDS cell map"; return; }
+    if (getenv("MAPF_JIT_FORCE_FAIL")) { e->jit_note = "MAPF_JIT_FORCE_FAIL is set (test knob)"; return; }
     const Hiprtc &rt = hiprtc_api();
     if (!rt.ok) { e->jit_note = "libhiprtc.so could not be loaded"; return; }
     const std::string dir = library_dir();
@@ -332,15 +363,50 @@ void jit_specialize(mapf_engine *e) {
     char tail_[64];
     snprintf(tail_, sizeof tail_, ", %d, %d", lpe, e->mask_w);
     const int wps = (lpe < 32 && e->dense) ? 4 : 0;
-    const std::string step_expr = std::string("mapfjit::k_step<mapfjit::") + inst + tail_ + ", " + std::to_string(wps) + ">";
+    const char *step_kernel = e->three_wave ? "k_step3" : "k_step";  // (three_wave implies wps == 0)
+    const std::string step_expr = std::string("mapfjit::") + step_kernel + "<mapfjit::" + inst + tail_ + ", " + std::to_string(wps) + ">";
     const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ">";
     const std::string key = std::to_string(c.device) + "|" + step_expr;
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(key);
     if (it == g_jit_cache.end()) {
         const auto t0 = std::chrono::steady_clock::now();
+        hipDeviceProp_t prop;
+        std::string arch = "gfx950";
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.gcnArchName[0]) {
+            arch = prop.gcnArchName;
+            arch = arch.substr(0, arch.find(':'));
+        }
+        // ---- the on-disk cache first
+        const std::string cdir = jit_cache_dir();
+        std::string cfile;
+        if (!cdir.empty()) {
+            uint64_t h = fnv1a(slurp(dir + "/mapf_kernels.inl"));
+            h = fnv1a(slurp(dir + "/../../include/mapf_step.h"), h);
+            h = fnv1a(step_expr + "|" + many_expr + "|" + arch + "|O3 c++17 kernarg-preload-16 v2", h);
+            char name[40];
+            snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
+            cfile = cdir + name;
+            const std::string code = slurp(cfile + ".co"), names = slurp(cfile + ".names");
+            const size_t nl = names.find('\n');
+            if (!code.empty() && nl != std::string::npos) {
+                JitModule m;
+                const std::string sn = names.substr(0, nl), mn = names.substr(nl + 1, names.find('\n', nl + 1) - nl - 1);
+                hipError_t hs = hipModuleLoadData(&m.mod, code.data());
+                if (hs == hipSuccess) hs = hipModuleGetFunction(&m.step, m.mod, sn.c_str());
+                if (hs == hipSuccess) hs = hipModuleGetFunction(&m.many, m.mod, mn.c_str());
+                if (hs == hipSuccess && m.step && m.many) {
+                    m.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    m.from_disk = true;
+                    it = g_jit_cache.emplace(key, m).first;
+                } else if (m.mod) {
+                    (void)hipModuleUnload(m.mod);  // (a damaged file: compile afresh and overwrite it)
+                }
+            }
+        }
+      if (it == g_jit_cache.end()) {
         std::string src = "#include \"mapf_step.h\"\n#include \"mapf_kernels.inl\"\nnamespace mapfjit {\n";
-        src += std::string("template __global__ void k_step<") + inst + tail_ + ", " + std::to_string(wps) +
+        src += std::string("template __global__ void ") + step_kernel + "<" + inst + tail_ + ", " + std::to_string(wps) +
                ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);\n";
         src += std::string("template __global__ void k_step_many<") + inst + tail_ +
                ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail, const int, const int, const ManyPolicy);\n}\n";
@@ -348,12 +414,6 @@ void jit_specialize(mapf_engine *e) {
         if (rt.create(&prog, src.c_str(), "mapf_jit.hip", 0, nullptr, nullptr) != 0) { e->jit_note = "hiprtcCreateProgram failed"; return; }
         rt.add_name(prog, step_expr.c_str());
         rt.add_name(prog, many_expr.c_str());
-        hipDeviceProp_t prop;
-        std::string arch = "gfx950";
-        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.gcnArchName[0]) {
-            arch = prop.gcnArchName;
-            arch = arch.substr(0, arch.find(':'));
-        }
         const std::string o_arch = "--offload-arch=" + arch, o_i1 = "-I" + dir, o_i2 = "-I" + dir + "/../../include";
         const char *opts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_i1.c_str(), o_i2.c_str(), "-mllvm", "-amdgpu-kernarg-preload-count=16",
                               "-Wno-unused-value", "-DMAPF_NS=mapfjit"};
@@ -374,6 +434,7 @@ void jit_specialize(mapf_engine *e) {
         const char *step_name = nullptr, *many_name = nullptr;
         rt.lowered(prog, step_expr.c_str(), &step_name);
         rt.lowered(prog, many_expr.c_str(), &many_name);
+        const std::string step_sym = step_name ? step_name : "", many_sym = many_name ? many_name : "";  // (prog owns the names)
         JitModule m;
         hipError_t hs = hipModuleLoadData(&m.mod, code.data());
         if (hs == hipSuccess && step_name) hs = hipModuleGetFunction(&m.step, m.mod, step_name);
@@ -385,12 +446,26 @@ void jit_specialize(mapf_engine *e) {
             return;
         }
         m.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!cfile.empty() && !step_sym.empty() && !many_sym.empty()) {  // best effort: write to a temporary name, then rename
+            mkdirs(cdir);
+            const std::string tmp = cfile + ".tmp" + std::to_string((long)getpid());
+            std::ofstream fc(tmp + ".co", std::ios::binary), fn(tmp + ".names");
+            fc.write(code.data(), (std::streamsize)code.size());
+            fn << step_sym << "\n" << many_sym << "\n";
+            fc.close();
+            fn.close();
+            if (fc.good() && fn.good()) {
+                (void)rename((tmp + ".co").c_str(), (cfile + ".co").c_str());
+                (void)rename((tmp + ".names").c_str(), (cfile + ".names").c_str());
+            }
+        }
         it = g_jit_cache.emplace(key, m).first;
+      }
     }
     e->jit_step = it->second.step;
     e->jit_many = it->second.many;
     char note[128];
-    snprintf(note, sizeof note, "compiled in %.1f s: ", it->second.seconds);
+    snprintf(note, sizeof note, it->second.from_disk ? "loaded from the on-disk cache in %.2f s: " : "compiled in %.1f s: ", it->second.seconds);
     e->jit_note = note + step_expr;
 }
 
@@ -399,7 +474,8 @@ hipError_t launch_jit_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     IoTail tail = static_cast<const IoTail &>(io);
     Io h = io;
     void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.bn8, &tail};
-    return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, step_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
+    return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, e->three_wave ? 192 : step_threads(e->lpe), 1, 1,
+                                 e->lds_bytes, s, args, nullptr);
 }
 hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
     const Params *pp = e->d_params;
@@ -447,6 +523,28 @@ static int alloc_device_state(mapf_engine *e);
 // Host writes to an env's stream or free-cell tables void the placements pre-drawn from them (kSlotInvalid).
 static hipError_t invalidate_slots(mapf_engine *e) {
     return hipMemset(e->p.next_sg, 0xFF, (size_t)e->p.B * e->p.N * sizeof(uint32_t));
+}
+// A pending (staged or valid) slot means: the env's stream array already holds the state AFTER the background draw and the
+// visible state sits in vis_rng (mapf_kernels.inl: kSlotInvalid).  Voiding such a slot without replacing the stream
+// (mapf_set_grids does: the free-cell tables changed, the stream did not) must put the visible state back, or the env
+// would silently skip one rng.choice draw.
+static int restore_visible_streams(mapf_engine *e) {
+    const int B = e->p.B, N = e->p.N;
+    HIP_TRY(e, hipDeviceSynchronize());
+    std::vector<uint32_t> slots((size_t)B * N);
+    std::vector<uint64_t> vis((size_t)B * 6), rng((size_t)B * 6);
+    HIP_TRY(e, hipMemcpy(slots.data(), e->p.next_sg, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(vis.data(), e->d_vis_rng, vis.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(rng.data(), e->d_rng, rng.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int b = 0; b < B; b++) {
+        if (slots[(size_t)b * N] != kSlotInvalid) {
+            memcpy(rng.data() + (size_t)b * 6, vis.data() + (size_t)b * 6, 6 * sizeof(uint64_t));
+            any = true;
+        }
+    }
+    if (any) HIP_TRY(e, hipMemcpy(e->d_rng, rng.data(), rng.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return MAPF_OK;
 }
 // After host writes to positions / goals / counters the MAY_FINISH hint of the last step is stale: force it on
 // (conservative: the sampler skips the env for one step, the next step writes the real hint).
@@ -567,6 +665,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // 8192 x 16x16 x 4 agents 6.2 us at 16 lanes, 5.9 us at 8; 1024 x 32x32 x 8 agents 5.4 us at 64)
         while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < 1024) lpe <<= 1;
     }
+#if defined(MAPF_DEV_C3) || defined(MAPF_SMALL_SHAPES)
+    if ((lpe != 4 && lpe != 8) || c.sensor_range > 2 || cte)
+        return fail(nullptr, MAPF_ERR_CONFIG, "this reduced build (development / checking) only holds groups of 4 and 8 lanes with windows up to 5 x 5");
+#endif
     mapf_engine *e = new mapf_engine();
     e->cfg = c;
     e->cte = cte;
@@ -579,28 +681,34 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     const int G = 64 / lpe;
     const int B = c.num_envs, N = c.num_agents, H = c.height, W = c.width;
     e->blocks = (B + G - 1) / G;
-    // finite episodes with sampled placements: the env's stream is consumed by reset() alone, so sampler workgroups
-    // behind the env workgroups of k_step pre-draw the next placement (mapf_kernels.inl: sampler_wave); each of their
-    // waves looks after 64 envs
-#ifndef MAPF_NO_SAMPLER_WG  // (A/B builds: no background sampler, every reset draws inline)
-    if (!cte && !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC))) {
-        e->sampler_blocks = sampler_blocks_for(B, step_threads(lpe) / 64);  // leading (specialised kernels) or trailing
-    }
-#endif
+    // Launch shape of the step kernel.  Finite episodes with sampled placements pre-draw the next placement in the
+    // background (the env's stream is consumed by reset() alone): kernels of the specialised small-group shapes
+    // (KFixed::kSlicedDraw: prebuilt, or compiled at creation) do it in slices inside the env workgroups, the others in
+    // sampler workgroups of the k_step grid (mapf_kernels.inl: sampler_wave; each of their waves looks after 64 envs).
+    // plan_grid(sliced) is called again when a requested run-time specialisation does not come about.
+    const bool finite_sampled = !cte && !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC));
     const int special_id = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
-    // the specialised finite kernels with N <= 8 draw in slices inside their observation waves (KFixed::kSlicedDraw)
-    if (special_id && e->sampler_blocks && c.num_agents <= 8) e->sampler_blocks = 0;
-    // a kernel compiled for this configuration (jit_specialize, below) draws in slices as well when N is 4 or 8
-    if (!special_id && !cte && (c.flags & MAPF_FLAG_JIT_SPECIALIZE) && !(c.flags & MAPF_FLAG_GENERIC_KERNEL) &&
-        lpe == pick_lpe(N) && (N == 4 || N == 8))
+    const bool small_full = (c.num_agents == 4 || c.num_agents == 8) && lpe == c.num_agents;
+    const bool jit_sliced = !special_id && !cte && (c.flags & MAPF_FLAG_JIT_SPECIALIZE) && !(c.flags & MAPF_FLAG_GENERIC_KERNEL) &&
+                            lpe == pick_lpe(N) && small_full && finite_sampled;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
+    auto plan_grid = [&](bool sliced) {
         e->sampler_blocks = 0;
-    {   // more than three waves per SIMD in one launch of the step kernel?  (k_step's WPS; 4 SIMDs per compute unit)
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
+#ifndef MAPF_NO_SAMPLER_WG  // (A/B builds: no background sampler, every reset draws inline)
+        if (finite_sampled && !sliced) e->sampler_blocks = sampler_blocks_for(B, step_threads(lpe) / 64);
+#endif
+        // more than three waves per SIMD in one launch of the step kernel?  (k_step's WPS; 4 SIMDs per compute unit)
         const int64_t waves = (int64_t)(e->blocks + e->sampler_blocks) * (step_threads(lpe) / 64);
         e->dense = waves > (int64_t)3 * 4 * cus;
         if (const char *f = getenv("MAPF_FORCE_DENSE")) e->dense = atoi(f) != 0;  // test knob: either build on any grid
-    }
+        // k_step3 (state / observation / aux wave): the sliced-draw shapes, while a launch has at most three waves per
+        // SIMD with three waves per workgroup (beyond that the two-wave kernel's 128-register build is the one that fits)
+        e->three_wave = sliced && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
+        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && atoi(f) != 0;  // test / A-B knob
+        if (e->three_wave) e->dense = 0;
+    };
+    plan_grid(small_full && finite_sampled && (special_id != 0 || jit_sliced));
 
     Params &p = e->p;
     memset(&p, 0, sizeof(p));
@@ -635,12 +743,17 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.scratch_i16 = p.hash_cap + 2 * N + 1;
     if (p.scratch_i16 < 2 * (4 * N + 2) + 4 * N + 2 * N + 8) p.scratch_i16 = 2 * (4 * N + 2) + 4 * N + 2 * N + 8;
     p.scratch_i16 = (p.scratch_i16 + 7) & ~7;  // 16-byte multiple
+    const int scratch_i16_alloc = p.scratch_i16;
+#ifdef MAPF_CHECK  // test knob of the checking build: DECLARE the groups' draw scratch too small (the allocation keeps its size), so
+                   // that tests/test_soak_gpu.py can see a check fire
+    if (getenv("MAPF_CHECK_SHRINK")) p.scratch_i16 -= 16;
+#endif
     p.ring_stride = (p.lw + 7) & ~7;  // 16-byte rows; <= 16 entries are preloaded whole by the step kernel
     const int rows_bytes = ((G * (H + 2 * kRowPad) * 8) + 15) & ~15;  // kRowPad sentinel rows on either side
     // one 16-byte entry per lane: pair table + two observation-wave tables, then 3 KiB for the record transpose
     const int tab_bytes = 3 * 64 * 16 + 64 * 48;
     const int stage_bytes = ((G * (cte ? (H * W + 5 * N) : N * p.L) * 4) + 15) & ~15;
-    const int scratch_bytes = ((G * p.scratch_i16 * 2) + 15) & ~15;
+    const int scratch_bytes = ((G * scratch_i16_alloc * 2) + 15) & ~15;
     p.lds_tab_off = rows_bytes;
     p.lds_stage_off = rows_bytes + tab_bytes;
     p.lds_scratch_off = rows_bytes + tab_bytes + stage_bytes;
@@ -657,22 +770,13 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // the wide specialisations are compiled for the cell-map path only (KFixed::kMapAlways)
         if (e->special && N > 16 && !e->use_map) e->special = 0;
     }
-    // k_step3: the specialised finite shapes with full groups of 4 or 8 lanes, while a launch has at most three waves per
-    // SIMD (three waves per workgroup: beyond that the two-wave kernel's 128-register build is the one that fits).
-    if (e->special && !e->sampler_blocks && !cte && (N == 4 || N == 8) && lpe == N &&
-        !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC))) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess || cus <= 0) cus = 256;
-        e->three_wave = (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus;
-        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->three_wave = e->three_wave && atoi(f) == 0;
-        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = atoi(f) != 0;  // test / A-B knob
-        if (e->three_wave) {
-            e->dense = 0;
-            e->lds_map_off = e->lds_bytes;  // (no cell map at these widths) 1 KiB for the aux wave's info / counter staging
-            e->lds_bytes += 1024;
-        }
+    // k_step3's aux wave stages the info rows and counters of its envs in 2 KiB of its own (no cell map at these widths:
+    // lds_map_off is free)
+    if (small_full && finite_sampled && lpe < 32) {
+        e->lds_map_off = e->lds_bytes;
+        e->lds_bytes += 2048;
     }
-    if (e->sampler_blocks) {  // the sampler workgroups of a k_step launch have their own LDS layout
+    if (finite_sampled) {  // the sampler workgroups of a k_step launch have their own LDS layout
         const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
         if (e->lds_bytes < need) e->lds_bytes = need;
     }
@@ -690,6 +794,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (c.flags & MAPF_FLAG_JIT_SPECIALIZE) {
         DeviceScope scope(c.device);
         jit_specialize(e);
+        if (jit_sliced && !e->jit_step) {  // no compiled kernel after all: the runtime-config kernels draw in sampler workgroups
+            plan_grid(false);
+            e->jit_note += " [runtime-config kernels, background draw in sampler workgroups]";
+        }
     }
     *out = e;
     return MAPF_OK;
@@ -799,6 +907,10 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
         }
     }
     ON_DEVICE(e);
+    {
+        const int rc = restore_visible_streams(e);  // (synchronises the device first)
+        if (rc != MAPF_OK) return rc;
+    }
     HIP_TRY(e, hipMemcpy(e->d_rows, rows.data(), rows.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_cells, cells.data(), cells.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_rank, rank.data(), rank.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -819,6 +931,7 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
 int mapf_set_rng_state(mapf_handle e, const uint64_t *rng_words) {
     if (!e || !rng_words) return fail(e, MAPF_ERR_CONFIG, "null argument");
     ON_DEVICE(e);
+    HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(e->d_rng, rng_words, (size_t)e->p.B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(e, invalidate_slots(e));
     return MAPF_OK;
@@ -1043,8 +1156,9 @@ int mapf_reset(mapf_handle e, const uint8_t *env_mask, float *obs, void *stream)
     return MAPF_OK;
 }
 
-int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
-              float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream) {
+static int step_impl(mapf_handle e, const int8_t *actions, const uint8_t *env_mask, float *obs, float *rewards,
+                     uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, float *final_obs,
+                     int32_t auto_reset, void *stream) {
     if (!e || !actions) return fail(e, MAPF_ERR_CONFIG, "null argument");
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_step");
     if (e->cte) return fail(e, MAPF_ERR_STATE, "handle was created with MAPF_FLAG_SINGLE_AGENT: use mapf_cte_step");
@@ -1077,12 +1191,25 @@ int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, 
     io.info_agent = info_agent;
     io.final_obs = final_obs;
     io.auto_reset = auto_reset;
+    io.env_mask = env_mask;
     io.stage_vals = e->d_stage_vals;
     io.free_cells = e->d_free_cells;
     io.vis_rng = e->d_vis_rng;
     ON_DEVICE(e);
     LAUNCH_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
     return MAPF_OK;
+}
+
+int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
+              float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream) {
+    return step_impl(e, actions, nullptr, obs, rewards, terminated, truncated, info_all, info_agent, final_obs, auto_reset, stream);
+}
+
+int mapf_step_masked(mapf_handle e, const int8_t *actions, const uint8_t *env_mask, float *obs, float *rewards,
+                     uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, float *final_obs,
+                     int32_t auto_reset, void *stream) {
+    if (!env_mask) return fail(e, MAPF_ERR_CONFIG, "null env_mask (use mapf_step)");
+    return step_impl(e, actions, env_mask, obs, rewards, terminated, truncated, info_all, info_agent, final_obs, auto_reset, stream);
 }
 
 static int step_many_impl(mapf_handle e, int32_t T, const int8_t *actions, const ManyPolicy &pol, float *obs,
@@ -1275,6 +1402,8 @@ int mapf_poll_error(mapf_handle e, void *stream, int32_t *env, int32_t *agent, i
             snprintf(buf, sizeof buf, "Invalid action %d for agent_%d (env %d)", rec[3], rec[2], rec[1]);
         else if (rec[0] == MAPF_ERR_NO_RESPAWN)
             snprintf(buf, sizeof buf, "No valid cell available for lifelong goal reassignment. (env %d, agent_%d)", rec[1], rec[2]);
+        else if (rec[0] == MAPF_ERR_INTERNAL)
+            snprintf(buf, sizeof buf, "checking build: index %d left its LDS region at site %d (env %d)", rec[3], rec[2], rec[1]);
         else if (rec[0] == MAPF_ERR_RNG_GUARD)
             snprintf(buf, sizeof buf, "bounded draw rejected 4096 times in a row: RNG state of env %d is corrupt", rec[1]);
         else

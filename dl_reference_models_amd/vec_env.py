@@ -240,18 +240,30 @@ class VecReferenceModel:
         self._check(self._lib.mapf_reset(self._h, mptr, C.c_void_p(self._obs.data_ptr()), self._stream()))
         return self._obs
 
-    def step(self, actions: torch.Tensor, auto_reset: bool = True, want_final_obs: bool = False) -> dict:
-        """One step of every env.  actions: int8 [B,N] on the env's device."""
+    def step(self, actions: torch.Tensor, auto_reset: bool = True, want_final_obs: bool = False,
+             env_mask: torch.Tensor | None = None) -> dict:
+        """One step of every env (or of those with env_mask != 0: the others are not touched at all -- state, generator,
+        counters, statistics, outputs).  actions: int8 [B,N] on the env's device."""
         if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
         if tuple(actions.shape) != (self.num_envs, self.num_agents):
             raise ValueError(f"actions must have shape {(self.num_envs, self.num_agents)}")
         fo = C.c_void_p(self._final_obs.data_ptr()) if (want_final_obs and auto_reset) else None
-        self._check(self._lib.mapf_step(
-            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
-            C.c_void_p(self._rewards.data_ptr()), C.c_void_p(self._terminated.data_ptr()),
-            C.c_void_p(self._truncated.data_ptr()), C.c_void_p(self._info_all.data_ptr()),
-            C.c_void_p(self._info_agent.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
+        if env_mask is not None:
+            env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if tuple(env_mask.shape) != (self.num_envs,):
+                raise ValueError(f"env_mask must have shape {(self.num_envs,)}")
+            self._check(self._lib.mapf_step_masked(
+                self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(env_mask.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                C.c_void_p(self._rewards.data_ptr()), C.c_void_p(self._terminated.data_ptr()),
+                C.c_void_p(self._truncated.data_ptr()), C.c_void_p(self._info_all.data_ptr()),
+                C.c_void_p(self._info_agent.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
+        else:
+            self._check(self._lib.mapf_step(
+                self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                C.c_void_p(self._rewards.data_ptr()), C.c_void_p(self._terminated.data_ptr()),
+                C.c_void_p(self._truncated.data_ptr()), C.c_void_p(self._info_all.data_ptr()),
+                C.c_void_p(self._info_agent.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
         return {
             "obs": self._obs, "rewards": self._rewards, "terminated": self._terminated, "truncated": self._truncated,
             "info_all": self._info_all, "info_agent": self._info_agent,

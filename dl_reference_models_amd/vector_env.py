@@ -14,8 +14,16 @@ per env per step -- as slow as the pure-Python reference.  Here the runner's env
                                          ``ReferenceModel.step`` returns (MA-env:695)
     vec.reset_at(b)                   -> (obs_dict, info_dict) of row b alone
 
-and the ``BaseEnv``-style trio RLlib's sampler drives (``poll`` / ``send_actions`` / ``try_reset``), so a
-maintainer can hand the object to a runner in place of the wrapper around per-object envs.
+and the ``BaseEnv``-style trio RLlib's OLD-stack sampler drives (``poll`` / ``send_actions`` / ``try_reset``).
+
+The reference itself runs RLlib's NEW stack (``src/agents/ppo.py:92-100``, ``impala.py``:
+``enable_env_runner_and_connector_v2=True``, ``num_envs_per_env_runner=4``), whose multi-agent env runner drives a vector
+object with ``num_envs``, ``envs``, ``reset(*, seed, options) -> (observations, infos)`` and
+``step(list_of_action_dicts) -> (observations, rewards, terminateds, truncateds, infos)`` with NEXT-STEP autoreset (a
+row that finished is reset by the following ``step`` call, which returns its reset observation, zero rewards and
+``False`` flags for it and ignores the action sent for it).  ``ReferenceModelAutoresetVectorEnv`` below offers that
+surface over the same single handle.  ``ray`` is not installed where this was written and tested, so both adapters are
+duck-typed against the documented interfaces; nobody has handed them to a live runner yet (INTEGRATION.md says so).
 
 Cost model: ONE kernel launch, ONE stream sync and TWO device->host copies (observations; one blob with
 rewards / done flags / info) per *vector* step, whatever ``num_envs`` is; per-env Python work is building
@@ -266,21 +274,16 @@ class ReferenceModelVectorEnv:
                     a = 5  # the kernel stops that env's agent loop there, like the reference (MA-env:504-506)
                 row[i] = a
         e = self._engine
+        self._acts_dev.copy_(self._acts, non_blocking=True)
         if all_rows:
-            self._acts_dev.copy_(self._acts, non_blocking=True)
             e.step(self._acts_dev, auto_reset=False)
         else:
-            # rows stepped alone: everybody else keeps its state -- a sub-batch step is a full step on a snapshot
-            # restored for the other rows (rare path: per-object callers)
-            keep = e.get_state()
-            self._acts_dev.copy_(self._acts, non_blocking=True)
-            e.step(self._acts_dev, auto_reset=False)
-            new = e.get_state()
-            sel = np.zeros(self.num_envs, dtype=bool)
-            sel[rows] = True
-            for k in keep:
-                new[k][~sel] = keep[k][~sel]
-            e.set_state(**new)
+            # rows stepped alone (per-object callers, rows waiting for a reset): the engine's per-env step mask leaves
+            # every other row untouched -- state, generator, counters, episode statistics, error latch
+            sel = np.zeros(self.num_envs, dtype=np.uint8)
+            sel[rows] = 1
+            self._mask_dev.copy_(torch.from_numpy(sel), non_blocking=False)
+            e.step(self._acts_dev, auto_reset=False, env_mask=self._mask_dev)
         self._state_cache = None
         obs_np = self._fetch()
         if first_bad is not None:
@@ -359,3 +362,48 @@ class ReferenceModelVectorEnv:
 
     def get_sub_environments(self):
         return self.envs
+
+
+class ReferenceModelAutoresetVectorEnv(ReferenceModelVectorEnv):
+    """The vector surface RLlib's new-stack multi-agent env runner drives (see the module docstring): ``num_envs``,
+    ``envs``, ``reset(*, seed=None, options=None)`` and ``step(action_dicts)`` with next-step autoreset, over ONE engine
+    handle.  A step in which no row restarts is one launch; a step in which some rows restart is two (the masked step of
+    the live rows, the masked reset of the finished ones)."""
+
+    def __init__(self, env_config: dict, num_envs: int):
+        super().__init__(env_config, num_envs)
+        self._needs_reset = np.zeros(self.num_envs, dtype=bool)
+
+    def reset(self, *, seed=None, options=None):
+        """``seed`` and ``options`` are ignored, as by the reference env (MA-env:440)."""
+        res = self.vector_reset()
+        self._needs_reset[:] = False
+        return [o for o, _ in res], [i for _, i in res]
+
+    def step(self, action_dicts):
+        if len(action_dicts) != self.num_envs:
+            raise ValueError(f"need one action dict per env ({self.num_envs})")
+        restart = np.flatnonzero(self._needs_reset).tolist()
+        live = [b for b in range(self.num_envs) if not self._needs_reset[b]]
+        out = [None] * self.num_envs
+        if live:
+            res = self._step_rows(live, [action_dicts[b] for b in live])
+            for b, r in zip(live, res):
+                out[b] = r
+                if r[2]["__all__"] or r[3]["__all__"]:
+                    self._needs_reset[b] = True
+        if restart:
+            sel = np.zeros(self.num_envs, dtype=np.uint8)
+            sel[restart] = 1
+            self._mask_dev.copy_(torch.from_numpy(sel), non_blocking=False)
+            self._engine.reset(self._mask_dev)
+            self._state_cache = None
+            obs_np = self._fetch(want_small=False)
+            obs, infos = self._obs_dicts(restart, obs_np)
+            zeros = dict.fromkeys(self.agents, 0.0)
+            flags = dict.fromkeys(list(self.agents) + ["__all__"], False)
+            for k, b in enumerate(restart):
+                out[b] = (obs[k], dict(zeros), dict(flags), dict(flags), infos[k])
+                self._needs_reset[b] = False
+                self._live[b] = True
+        return tuple(list(col) for col in zip(*out))

@@ -81,6 +81,8 @@ extern "C" {
 #define MAPF_ERR_CONFIG (-4)      /* config outside this build's limits / inconsistent arguments */
 #define MAPF_ERR_HIP (-5)         /* a HIP runtime call failed */
 #define MAPF_ERR_STATE (-6)       /* call sequence error (e.g. step before grids were set) */
+#define MAPF_ERR_INTERNAL (-8)    /* checking build only (-DMAPF_CHECK): an index left the LDS region it belongs to; env, site
+                                   * id and the offending value are latched like the device errors above */
 #define MAPF_ERR_RNG_GUARD (-7)   /* device: a bounded draw was rejected 4096 times in a row (cannot happen with a sound
                                    * stream state, p < 1e-24000): the env's RNG state is corrupt; latched like the others */
 
@@ -208,6 +210,15 @@ int mapf_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *obs /
  * the reset observation. */
 int mapf_step(mapf_handle h, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
               float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream);
+
+/* mapf_step for a SUBSET of the envs: env_mask (device uint8 [B]) selects the envs that step; every other env is not
+ * touched at all -- state, generator, counters, episode statistics, error latch -- and its rows of the outputs are
+ * left as they are.  This is what stepping ONE of several reference env objects means (RLlib's runners step their
+ * sub-envs one by one, and skip the ones that wait for a reset: MultiAgentEnv.step per object, MA-env:474); the vector
+ * adapters use it for rows stepped alone and for the next-step autoreset of the new-stack vector protocol. */
+int mapf_step_masked(mapf_handle h, const int8_t *actions, const uint8_t *env_mask, float *obs, float *rewards,
+                     uint8_t *terminated, uint8_t *truncated, float *info_all, uint8_t *info_agent, float *final_obs,
+                     int32_t auto_reset, void *stream);
 
 /* T consecutive steps in ONE launch (state stays in registers, obstacle rows in LDS): what the reference's
  * env-only benchmark loop does when the actions do not depend on the observations

@@ -112,7 +112,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    so = build()
+    so = os.environ.get("MAPF_ORACLE_SO") or build()  # MAPF_ORACLE_SO: the sanitizer build (make asan), tests/test_oracle_asan.py
     L = C.CDLL(so)
     vp, i32, u64, u32 = C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32
     L.mo_obs_len.restype = C.c_int

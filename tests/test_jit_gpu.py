@@ -81,3 +81,31 @@ def test_prebuilt_specialisations_and_opt_outs_are_left_alone():
     info = VecReferenceModel(dict(cfg, jit_specialize=True, force_generic_kernel=True)).launch_info()
     assert info["specialized_kernel"] == 0 and not info["jit"]
     assert not VecReferenceModel(cfg).launch_info()["jit"]
+
+
+# The table tools/jit_bisect.py walks (it found the 16-round cap of the straight-line observation copy): one hard
+# configuration -- 64 agents, 9 x 9 windows, one-step livelock window, fractional epsilon -- and a dozen variations of it,
+# each through kernels compiled for it and through the runtime-config kernels, against the oracle.
+_BISECT_BASE = {"env_name": "synthetic", "num_agents": 64, "sensor_range": 4, "steps_per_episode": 61, "normalize_goal_delta": False,
+                "include_goal_distance": False, "include_action_mask_in_obs": True, "include_blocking_pressure_in_obs": True,
+                "lifelong_mapf": False, "enable_lock_metrics": True, "deadlock_window_steps": 37, "livelock_window_steps": 1,
+                "lock_nearby_manhattan": 3, "lock_min_neighbors": 3, "lock_progress_epsilon": 3.7}
+_BISECT = {"as failed": {}, "sr2": {"sensor_range": 2}, "sr3": {"sensor_range": 3}, "lifelong": {"lifelong_mapf": True},
+           "lw16 dw8": {"deadlock_window_steps": 8, "livelock_window_steps": 16},
+           "nearby2 minn1": {"lock_nearby_manhattan": 2, "lock_min_neighbors": 1}, "N40": {"num_agents": 40},
+           "N33 sr4": {"num_agents": 33}, "N20 sr4": {"num_agents": 20}, "N12 sr4": {"num_agents": 12},
+           "sr5": {"sensor_range": 5}, "sr4 no mask": {"include_action_mask_in_obs": False}}
+
+
+@pytest.mark.parametrize("name", sorted(_BISECT))
+def test_bisect_table_compiled_and_runtime_kernels_match_the_oracle(name):
+    cfg = dict(_BISECT_BASE, **_BISECT[name])
+    N, B = cfg["num_agents"], 15
+    grids = synth_grids(B, 28, 28, 0.0, N, base_seed=1)
+    seeds = list(range(B))
+    acts = np.random.default_rng(3).integers(0, 5, size=(40, B, N)).astype(np.int8)
+    for jit in (True, False):
+        eng = EngineStepper(grids, cfg, seeds=seeds, jit_specialize=jit)
+        info = eng.env.launch_info()
+        assert info["jit"] == jit, info["jit_note"]
+        compare_steppers(eng, OracleStepper(grids, cfg, seeds=seeds), acts)

@@ -14,15 +14,45 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("master,cases,only_n,dense", [(2026, 40, None, None), (77, 30, 4, None), (4711, 30, None, "1"),
-                                                       (1616, 25, 16, None), (1617, 15, 16, "1")])
-def test_short_soak_matches_oracle(master, cases, only_n, dense, monkeypatch):
-    """dense = "1": the 128-register build of the specialised step kernels (k_step's WPS = 4: no speculative slice
-    loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per
-    SIMD (MAPF_FORCE_DENSE is read by mapf_create)."""
+@pytest.mark.parametrize("master,cases,only_n,dense,check", [
+    (2026, 40, None, None, False), (77, 30, 4, None, False), (4711, 30, None, "1", False), (1616, 25, 16, None, False),
+    (1617, 15, 16, "1", False), (2027, 30, None, None, True), (2028, 15, None, "1", True)])
+def test_short_soak_matches_oracle(master, cases, only_n, dense, check, monkeypatch):
+    """dense = "1": the 128-register two-wave build of the specialised step kernels (k_step's WPS = 4: no speculative
+    slice loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per
+    SIMD (MAPF_FORCE_DENSE is read by mapf_create); without it the small-group shapes run the three-wave kernel.
+    check: the same soak on the CHECKING build (-DMAPF_CHECK: every data-dependent LDS scatter / gather index of the
+    draw, the inline reset and the staging rows is range-checked against its lane group's region and latches
+    MAPF_ERR_INTERNAL): the build that would have reported round 2's draw_shuffle16 bug at the store instead of 200 cases
+    later as a wrong goal cell."""
     from soak_specialized import run_soak
     if dense is not None:
         monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
+    if check:
+        monkeypatch.setenv("MAPF_CHECK_BUILD", "1")
     lines = []
-    err = run_soak(master, cases, only_n=only_n, log=lines.append)
+    err = run_soak(master, cases, only_n=only_n, log=lines.append, poll_errors=check)
     assert err is None, err + "\n" + "\n".join(lines[-8:])
+
+
+def test_checking_build_latches_an_index_outside_its_region(monkeypatch):
+    """The checking build is not a no-op: a scratch region deliberately declared too small (MAPF_CHECK_SHRINK, read by
+    mapf_create of the checking build only) trips site 10 at the first inline reset."""
+    import numpy as np
+    import torch
+
+    from dl_reference_models_amd import _lib as L
+    from dl_reference_models_amd.vec_env import VecReferenceModel
+    from trace_util import synth_grids
+
+    monkeypatch.setenv("MAPF_CHECK_BUILD", "1")
+    monkeypatch.setenv("MAPF_CHECK_SHRINK", "1")
+    B, n = 16, 8
+    env = VecReferenceModel({"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "steps_per_episode": 2, "num_envs": B,
+                             "include_action_mask_in_obs": True, "grid": synth_grids(B, 10, 10, 0.1, n), "seeds": list(range(B))})
+    env.reset()
+    a = torch.zeros((B, n), dtype=torch.int8, device=env.device)
+    with pytest.raises(RuntimeError, match="checking build"):
+        for t in range(6):
+            env.step(a)
+            env.poll_error()

@@ -18,7 +18,8 @@ import numpy as np
 from trace_util import EngineStepper, OracleStepper, _eq, synth_grids
 
 
-def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, only=-1, watch=None, log=print):
+def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, only=-1, watch=None, log=print,
+             poll_errors=False):
     """Returns None when every case matched, else the failure text."""
     rng = np.random.default_rng(master)
     t0 = time.time()
@@ -74,6 +75,8 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
                 ra, rb = eng.step(a), orc.step(a)
                 if ra is None:
                     continue
+                if poll_errors:  # (checking build: an index that left its LDS region is latched like a device error)
+                    eng.env.poll_error()
                 bad = np.argwhere(ra["obs"] != rb["obs"])
                 if len(bad):
                     e = int(bad[0][0])
@@ -92,7 +95,7 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
                     _eq("positions", eng.positions(), orc.positions(), t)
                     _eq("goals", eng.goals(), orc.goals(), t)
                     _eq("rng words", eng.rng_words(), orc.rng_words(), t)
-        except AssertionError as exc:
+        except (AssertionError, RuntimeError) as exc:
             return (f"FAIL case {case} of master seed {master}: cfg={cfg} B={B} HxW={H}x{W} density={density} "
                     f"want_final={want_final} greedy={greedy}: {exc}")
         if case % 20 == 0:
