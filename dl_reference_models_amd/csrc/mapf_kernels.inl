@@ -173,6 +173,9 @@ struct IoTail {
     uint32_t *stage_vals;
     const uint16_t *free_cells;
     uint64_t *vis_rng;
+    const uint64_t *jump_c;      // [B][16][2] per env: S_q * inc mod 2^128 (hi, lo), q = 1 .. 16 -- the increment of a
+                                 // PCG64 stream never changes, so this half of the jump-ahead (state_q = A_q * state +
+                                 // S_q * inc) is a table written when the stream is set (mapf_set_rng_state / set_state)
 };
 struct Io : IoHead, IoTail {
     int col_pad;  // kRowPad when the rows carry low sentinel bits (W <= 64 - 2 * kRowPad), else 0; a function of W
@@ -745,6 +748,14 @@ __device__ __forceinline__ void store_lane_hist(uint2 *hot, uint32_t bn8, size_t
     store_state16(p2 + idx, make_uint4((uint32_t)st.progress, (uint32_t)(st.progress >> 32), st.dist.x, st.dist.y));
     p3[idx] = make_uint2(st.dist.z, st.dist.w);
 }
+// the same as <wave-uniform first agent> + <lane>: the plane addresses stay scalar, the lane offset 32 bits
+__device__ __forceinline__ void store_lane_hist(uint2 *hot, uint32_t bn8, size_t idx0, int lane, const Lane &st) {
+    uint4 *p1 = const_cast<uint4 *>(agent_plane16(hot, bn8, 1)) + idx0, *p2 = const_cast<uint4 *>(agent_plane16(hot, bn8, 2)) + idx0;
+    uint2 *p3 = reinterpret_cast<uint2 *>(const_cast<uint4 *>(agent_plane16(hot, bn8, 3))) + idx0;
+    store_state16(p1 + lane, make_uint4((uint32_t)st.moved, (uint32_t)(st.moved >> 32), (uint32_t)st.failed, (uint32_t)(st.failed >> 32)));
+    store_state16(p2 + lane, make_uint4((uint32_t)st.progress, (uint32_t)(st.progress >> 32), st.dist.x, st.dist.y));
+    p3[lane] = make_uint2(st.dist.z, st.dist.w);
+}
 // the whole agent; `myrows` = the env's obstacle rows in LDS (for the pass bits of st.pos)
 __device__ __forceinline__ void store_lane(uint2 *hot, uint32_t bn8, size_t idx, const Lane &st, const uint64_t *myrows,
                                            int col_pad, int W) {
@@ -1047,7 +1058,8 @@ constexpr int kObsEmit = 0, kObsBoth = 1, kObsPairs = 2;
 template <class K, int LPE, int MW, int MODE, bool USE_MAP = false>
 __device__ __forceinline__ void observe(const Params &p, const Io &io, const uint64_t *lrows, const uint4 *tabg, float *srow,
                                         bool is_agent, int a, uint32_t cur, uint32_t goal, bool final_state,
-                                        bool pressure, int my_delta, PairOut &po, const uint32_t *map = nullptr) {
+                                        bool pressure, int my_delta, PairOut &po, const uint32_t *map = nullptr,
+                                        const float *gd_lut = nullptr) {
     constexpr bool FULL = MODE != kObsEmit, EMIT = MODE != kObsPairs;
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
     constexpr int C = LPE < 8 ? LPE : 8;
@@ -1167,8 +1179,12 @@ __device__ __forceinline__ void observe(const Params &p, const Io &io, const uin
     own.clear();
     window_set<MW>(own, goal, r0, c0, V);
     const bool norm = (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
-    emit_obs_row<K, MW, MAXV>(p, srow, obst, agm, goals, own, goal_delta((int)((goal >> 8) & 255u) - myr, io.den_r, norm),
-                              goal_delta((int)(goal & 255u) - myc, io.den_c, norm), pressure);
+    const int gdr = (int)((goal >> 8) & 255u) - myr, gdc = (int)(goal & 255u) - myc;
+    // gd_lut (k_step3's observation wave): the quotients of every possible delta, computed -- with the same correctly
+    // rounded divide -- while the wave waited for the moves; two LDS reads instead of two divide sequences behind B1
+    const float gd_r = gd_lut ? gd_lut[gdr + 63] : goal_delta(gdr, io.den_r, norm);
+    const float gd_c = gd_lut ? gd_lut[128 + gdc + 63] : goal_delta(gdc, io.den_c, norm);
+    emit_obs_row<K, MW, MAXV>(p, srow, obst, agm, goals, own, gd_r, gd_c, pressure);
 }
 
 // copy the wave's staged observations to global memory.  sel (per lane, uniform inside a group):
@@ -1321,6 +1337,8 @@ struct PcgPre {  // fetched ahead by the caller (background sampler): stream sta
     Pcg g;
     int pop;
     uint4 ja, js;  // {hi.lo32, hi.hi32, lo.lo32, lo.hi32} as stored in kPcgJumpA / kPcgJumpS
+    bool have_cq = false;  // sliced draw: `ja` is A_q of the ONE output this lane computes in this pass and `cq` the env's
+    uint4 cq = {0, 0, 0, 0};  // S_q * inc from Io::jump_c (same word order): one 128-bit product per output instead of two
 };
 // First half: the raw outputs (jump-ahead) and all bounded draws -> vals[4N - 1] in the group's scratch.  Returns
 // whether the lane-parallel draw stands (else: sequential restatement); then the stream after the draws is in
@@ -1370,7 +1388,11 @@ __device__ __forceinline__ bool draw_stage_a(const Params &p, int16_t *scr, int 
     U128 st = s0, fin = s0;
     uint32_t fin_hi32 = 0;
     for (int q = a + 1 + (qpass == 1 ? LPE : 0); mode != 2 && q <= nout; q += LPE) {
-        if (q == a + 1 || qpass == 1) {
+        if (pre.have_cq) {
+            const U128 ja = {(uint64_t)pre.ja.x | ((uint64_t)pre.ja.y << 32), (uint64_t)pre.ja.z | ((uint64_t)pre.ja.w << 32)};
+            const U128 cq = {(uint64_t)pre.cq.x | ((uint64_t)pre.cq.y << 32), (uint64_t)pre.cq.z | ((uint64_t)pre.cq.w << 32)};
+            st = add128(mul128(ja, s0), cq);
+        } else if (q == a + 1 || qpass == 1) {
             U128 ja = {kPcgJumpA[q][0], kPcgJumpA[q][1]}, js = {kPcgJumpS[q][0], kPcgJumpS[q][1]};
             if (pre.have && qpass != 1) {
                 ja = U128{(uint64_t)pre.ja.x | ((uint64_t)pre.ja.y << 32), (uint64_t)pre.ja.z | ((uint64_t)pre.ja.w << 32)};
@@ -2013,6 +2035,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (obs_wave && !lifelong && !use_map) {  // finite episodes: goals are fixed, the observation only waited for the moves
         otabg[a] = obs_entry(false);
         wg_sync();  // B1
+#ifdef MAPF_K2_PRIO_STATE
+        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
+#endif
         MAPF_STAMP(19);  // (sub-stamp: finite mode, observation wave released)
     }
 
@@ -2172,6 +2197,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (obs_wave && lifelong && !use_map) {  // respawned goals are part of the observation: publish after the goal logic
         otabg[a] = obs_entry(reassigned);
         wg_sync();  // B1
+#ifdef MAPF_K2_PRIO_STATE
+        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
+#endif
     }
     if (use_map) {
         // large N: every agent ORs its remaining fields into the env's cell map (owner-old went in before the move),
@@ -2189,6 +2217,9 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (obs_wave) {  // the observation wave reads its window from the map: release it when the map is complete
             otabg[a] = obs_entry(reassigned);
             wg_sync();  // B1
+#ifdef MAPF_K2_PRIO_STATE
+        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
+#endif
         } else {
             wave_lds_sync();
         }
@@ -2437,13 +2468,17 @@ __device__ __forceinline__ Lds with_parity(const Lds &l, int t) {
 // sampling, which only touches the group's scratch, runs before B2).
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                              const int ngroups, const bool past_b1 = false) {
+                                              const int ngroups, const bool past_b1 = false,
+                                              const float *gd_lut = nullptr) {
     const int grp = lane / LPE, a = lane % LPE;
     const int N = K::N(p), H = io.H;
     const uint4 *otabg = l.otab + grp * LPE;
     const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = l.stage + (size_t)(grp * N + min(a, N - 1)) * K::L(p);
     if (!past_b1) wg_sync();  // B1
+#ifdef MAPF_K2_PRIO_OBS
+    if (!past_b1) __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_OBS);
+#endif
     MAPF_STAMP_W1(11);
     const uint4 ent = otabg[a];
     const uint32_t w = ent.w;
@@ -2454,10 +2489,10 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
         const int map_w = io.W + 2 * kRowPad;
         observe<K, LPE, MW, kObsEmit, MAP_OK>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
                                               (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po,
-                                              l.map + grp * (H + 2 * kRowPad) * map_w);
+                                              l.map + grp * (H + 2 * kRowPad) * map_w, gd_lut);
     } else {
         observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent, a, ent.x >> 16, ent.y & 0xFFFFu,
-                                             (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po);
+                                             (w & kObsWFinal) != 0, (w & kObsWPressure) != 0, 0, po, nullptr, gd_lut);
     }
     wave_lds_sync();
     MAPF_STAMP_W1(12);
@@ -2479,7 +2514,8 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
         wave_lds_sync();
         if (fr) mine[a] = make_uint4(rpos | (rpos << 16), rgoal, ent.z, w);
         wave_lds_sync();
-        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent && fr, a, rpos, rgoal, true, false, 0, po);
+        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, otabg, srow, is_agent && fr, a, rpos, rgoal, true, false, 0, po,
+                                             nullptr, gd_lut);
         wave_lds_sync();
         flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, fr ? 0 : 2);
     }
@@ -2507,7 +2543,13 @@ struct DrawReq {
     uint4 rq;          // slices 1, 2: the stream the outputs are computed from, 16 bytes each in lanes 0 .. 2 of the group
     int pop;           // free-cell count
     uint32_t sv[5];    // slices 3..7: stage_vals dwords a + i * LPE
+    uint4 ja[2], cq[2];  // slices 1, 2: A_q (kPcgJumpA) and the env's S_q * inc (Io::jump_c) for q = a + 1 + LPE and q = a + 1
 };
+__device__ __forceinline__ void draw_request_jump(const Io &io, int a, int env, int LPE, int which, DrawReq &d) {
+    const int q = a + 1 + (which == 0 ? LPE : 0);  // index 0: slice 1 (the later half), 1: slice 2
+    d.ja[which] = *reinterpret_cast<const uint4 *>(&kPcgJumpA[min(q, 64)][0]);
+    d.cq[which] = reinterpret_cast<const uint4 *>(io.jump_c)[(size_t)env * 16 + min(q, 16) - 1];
+}
 // With the wave's first loads: the env's slot word and hint, and -- speculatively, 116 bytes per env and launch, so that
 // a slice starts computing at B0 instead of a memory round trip later (it has to be done by B1) -- the free-cell count,
 // the first two staging dwords of every lane (all that slices 4 .. 7 read) and the visible stream (slice 2).
@@ -2520,7 +2562,10 @@ __device__ __forceinline__ void draw_request_head(const Io &io, int N, int a, in
     d.pop = 2 * N + 1;
     d.sv[0] = d.sv[1] = 0;
     d.rq = make_uint4(0, 0, 0, 0);
+    d.ja[0] = d.ja[1] = d.cq[0] = d.cq[1] = make_uint4(0, 0, 0, 0);
     if (SPEC) {
+        draw_request_jump(io, a, env, LPE, 0, d);
+        draw_request_jump(io, a, env, LPE, 1, d);
         d.pop = free_counts_of(io.scal, io.B, N)[env];
         const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
         d.sv[0] = sv[a];
@@ -2556,10 +2601,12 @@ __device__ __forceinline__ int draw_request_body(const Params &p, const Io &io, 
         if (__any(stage == 1)) {  // the stream before the draw is the env's own (slice 2: vis_rng, fetched with the head)
             const uint4 *rw = reinterpret_cast<const uint4 *>(streams_of(io.scal, io.B, N) + (size_t)env * 6);
             if (stage == 1) d.rq = rw[min(a, 2)];
+            if (!SPEC) draw_request_jump(io, a, env, LPE, 0, d);
         }
         if (!SPEC && __any(stage == 2)) {
             const uint4 *rw = reinterpret_cast<const uint4 *>(io.vis_rng + (size_t)env * 6);
             if (stage == 2) d.rq = rw[min(a, 2)];
+            draw_request_jump(io, a, env, LPE, 1, d);
         }
         if (__any(stage >= 3)) {
             const uint32_t *sv = io.stage_vals + (size_t)env * stage_dwords(N);
@@ -2597,11 +2644,13 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         pre.g.has32 = gshfl<LPE>(d.rq.x, 2);
         pre.g.uinteger = gshfl<LPE>(d.rq.z, 2);
         pre.pop = d.pop;
-        pre.ja = *reinterpret_cast<const uint4 *>(&kPcgJumpA[a + 1][0]);
-        pre.js = *reinterpret_cast<const uint4 *>(&kPcgJumpS[a + 1][0]);
-        int pop_unused;
         // (one kind of slice per wave and launch: `stage` is wave-uniform among the groups that are on)
         const int qpass = __any(stage == 1) ? 1 : 0;
+        pre.js = make_uint4(0, 0, 0, 0);
+        pre.have_cq = true;  // one 128-bit product per output: A_q * state + (S_q * inc from the env's table)
+        pre.ja = d.ja[qpass == 1 ? 0 : 1];
+        pre.cq = d.cq[qpass == 1 ? 0 : 1];
+        int pop_unused;
         const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, on, on, N, io.vis_rng, pre, p.rng, pop_unused, -1, 1,
                                           streams_of(io.scal, io.B, N), qpass, sv);
         if (on && ok && a == 0) slot[0] = qpass == 1 ? kSlotStaged : kSlotStaged2;
@@ -2985,7 +3034,9 @@ __global__ __launch_bounds__(step_threads(LPE), (LPE >= 32 ? 2 : (WPS ? WPS : 1)
 // half-row mirror (lane i <-> 7 - i = i ^ 7), all full-rate DPP moves
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_get(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    // (mov_dpp: no tied `old` operand, so no register copy in front of every DPP move; all source lanes of these
+    //  patterns are live, bound_ctrl never matters)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 template <int LPE>
 __device__ __forceinline__ void group_xchg(const uint32_t v, uint32_t (&o)[LPE - 1]) {
@@ -3134,12 +3185,20 @@ __device__ __forceinline__ uint32_t obs_flags_for(const Io &io, const EndDecisio
 // after B1 this kernel is bound by instruction issue on the SIMD, not by any wave's latency: 5.67 against 5.40 us.)
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                          const uint2 hot, const uint32_t nsg, const int step_count_in) {
+                                          const uint2 hot, const uint32_t nsg, const int step_count_in, float *gd_lut) {
     constexpr int G = 64 / LPE;
     const int N = K::N(p);
     const uint32_t goal_real = hot.x >> 16;
     const bool pressure_real = ((hot.y >> 16) & kFlagPressure) != 0;
-    wg_sync();  // B1: the moves
+    {   // while the moves are being resolved: the goal-delta quotients (MA-env:330-335) of every delta a <= 64 x 64 grid has
+        const bool norm = (K::flags(p) & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
+#pragma unroll
+        for (int k = lane; k < 128; k += 64) {
+            gd_lut[k] = goal_delta(k - 63, io.den_r, norm);
+            gd_lut[128 + k] = goal_delta(k - 63, io.den_c, norm);
+        }
+    }
+    wg_sync();  // B1: the moves (and, LDS being drained before the barrier, the table above)
     // After B1 the workgroup's SIMDs are issue-bound (three busy waves each).  The observation wave goes first: its
     // stream is what the launch ends with, and the aux wave's work then fills the slots under that stream's drain.
     __builtin_amdgcn_s_setprio(3);  // (measured, us per step staggered / synchronised: obs 3, aux 1, slice 0: 5.52 / 5.08;
@@ -3156,7 +3215,7 @@ __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const L
     }
     l.otab[lane] = mine;
     wave_lds_sync();
-    obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true);
+    obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true, gd_lut);
 }
 
 // ---- wave 2 of k_step3 -------------------------------------------------------------------------------------------
@@ -3175,7 +3234,7 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
     const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
     const bool dist_in_rec = lw <= 16;
-    const size_t idx = (size_t)env0 * N + lane;
+    const size_t idx0 = (size_t)env0 * N;  // wave-uniform: the stores below are <uniform base> + <lane> (no 64-bit vector math)
     const uint64_t *myrows = l.rows + grp * (io.H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
 
     MAPF_STAMP_W2(21);
@@ -3246,16 +3305,16 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     {
         const float term_reward = !done ? 0.0f : (!dec.trunc ? 1.0f : (dec.on_goal ? 0.0f : -1.0f));
         const float reward = (as.grs ? 0.5f : 0.0f) + term_reward;
-        if (io.rewards) io.rewards[idx] = reward;
+        if (io.rewards) (io.rewards + idx0)[lane] = reward;
         if (io.info_agent) {
             uchar2 ia;
             ia.x = blocking ? 1 : 0;
             ia.y = as.grs ? 1 : 0;
-            reinterpret_cast<uchar2 *>(io.info_agent)[idx] = ia;
+            (reinterpret_cast<uchar2 *>(io.info_agent) + idx0)[lane] = ia;
         }
         if (a == 0) {
-            if (io.terminated) io.terminated[env] = (uint8_t)dec.term;
-            if (io.truncated) io.truncated[env] = (uint8_t)dec.trunc;
+            if (io.terminated) (io.terminated + env0)[grp] = (uint8_t)dec.term;
+            if (io.truncated) (io.truncated + env0)[grp] = (uint8_t)dec.trunc;
         }
         Lane img;
         img.pos = cur;
@@ -3268,11 +3327,11 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
                 img.goal = nsg >> 16;
                 img.pos = img.start;
                 img.flags = 0u;
-                slots_of(io.scal, io.B)[idx] = kSlotInvalid;  // consumed
+                (slots_of(io.scal, io.B) + idx0)[lane] = kSlotInvalid;  // consumed
             }
         }
         // (an env that draws inline -- slow reset -- gets its hot plane from the state wave, which makes the draw)
-        if (!dec.slow_reset) store_lane_hot(io.agents, idx, img, agent_pass_bits(myrows, img.pos, io.col_pad, io.W));
+        if (!dec.slow_reset) store_lane_hot(io.agents + idx0, (size_t)lane, img, agent_pass_bits(myrows, img.pos, io.col_pad, io.W));
     }
     MAPF_STAMP_W2(24);
 
@@ -3347,7 +3406,7 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
             img.moved = img.failed = img.progress = 0ull;
             img.dist = make_uint4(0, 0, 0, 0);
         }
-        store_lane_hist(io.agents, io.bn8, idx, img);
+        store_lane_hist(io.agents, io.bn8, idx0, lane, img);
     }
     MAPF_STAMP_W2(30);
     // episode statistics (callbacks.py:236-345), as step_body
@@ -3458,7 +3517,8 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
             if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
             return;
         }
-        if (io.obs || io.final_obs) obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1);
+        if (io.obs || io.final_obs)
+            obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1, reinterpret_cast<float *>(lds_raw + io.lds_map_off + 2048));
         else wg_sync();  // B1 (the other waves read the rows behind it)
         return;
     }
@@ -3479,6 +3539,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         dreq.pop = 2 * N + 1;
         dreq.sv[0] = dreq.sv[1] = 0;
         dreq.rq = make_uint4(0, 0, 0, 0);
+        dreq.ja[0] = dreq.ja[1] = dreq.cq[0] = dreq.cq[1] = make_uint4(0, 0, 0, 0);
     } else {
         lane_issue_hist(io.agents, io.bn8, idx, raw);
         load_scal(io.scal, env, sc);
@@ -3517,8 +3578,10 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         MAPF_STAMP(1);
         state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, raw.h, sc[0], nsg);
         // The background draw of the next placement (draw_slice), one slice per launch, runs HERE: this wave has nothing
-        // else to do once the moves are out, and its inputs came with the wave's first loads.  (The window before B1,
-        // where round 2 ran it in the observation wave, closed when B1 moved from 5.5 k to under 3 k cycles.)
+        // else to do once the moves are out.  (The window before B1, where round 2 ran it in the observation wave, closed
+        // when B1 moved from 5.5 k to under 3 k cycles: run there by the aux wave -- inputs fetched with its first loads,
+        // outputs at one 128-bit product each -- a slice still takes 1.7-2.6 k cycles of LDS staging and round trips and
+        // holds B1 up for its workgroup: 6.25 us per staggered step against 5.6 here.)
         {
             dreq.w0 = group_bcast<0, LPE>(nsg);
             const int d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
@@ -3591,8 +3654,12 @@ __device__ __forceinline__ int masked_random_action(uint64_t seed, uint32_t agen
     return act;
 }
 
-template <class K, int LPE, int MW>
-__global__ __launch_bounds__(many_threads(LPE)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
+// WPS: as k_step's -- the register budget in waves per SIMD (0: none).  The fused kernel's loop keeps state, counters and
+// both bodies live and takes ~220 VGPRs unconstrained (two waves per SIMD): right for grids of at most two waves per SIMD
+// (c3: 8 192 envs), wrong beyond, where half of the workgroups waited for a second round (16 384 envs: 9.6 us per step
+// fused against 7.7 with single launches).  mapf_create picks the 128-register build for such grids (mapf_engine::dense).
+template <class K, int LPE, int MW, int WPS = 0>
+__global__ __launch_bounds__(many_threads(LPE), (WPS ? WPS : 1)) void k_step_many(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
                                                                  const IoTail tail, const int T, const int obs_mode,
                                                                  const ManyPolicy pol) {
     const Params &p = *pp;
@@ -4046,6 +4113,8 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
                                       MAPF_FLAG_LOCK_METRICS;  // the reference's default obs, L = 28
 #if defined(MAPF_DEV_C3)  // development builds (mapf_step.hip): the headline shape only
 #define MAPF_SPECIALIZATIONS(X) X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)
+#elif defined(MAPF_DEV_C5)
+#define MAPF_SPECIALIZATIONS(X) X(3, 64, 2, (kFlagsHeadline | MAPF_FLAG_LIFELONG), 8, 16, 2, 1, 64)
 #elif defined(MAPF_SMALL_SHAPES)  // the checking build
 #define MAPF_SPECIALIZATIONS(X)                 \
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)   \
@@ -4060,6 +4129,13 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
     X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8)                            \
     X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)                            \
     X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)  /* the reference's own training setup, main.py:55-67: 16 agents, 7x7 */
+#endif
+
+// The headline kernel is instantiated HERE, ahead of everything the host dispatchers instantiate: it then leads the code
+// object.  (The same kernel measured 1.5-4 % slower from deeper inside the library's code object than from a small one,
+// DESIGN.md 4 "Run-time specialisation" and 5b; where it sits is the one difference.)
+#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5)
+template __global__ void k_step3<KFixed<8, 2, kFlagsHeadline, 8, 16, 2, 1>, 8, 32, 0>(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);
 #endif
 
 }  // namespace

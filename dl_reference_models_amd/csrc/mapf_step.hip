@@ -54,6 +54,9 @@
 #if defined(MAPF_DEV_C3)
 #define MAPF_FOR_LPE(X) X(8)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
+#elif defined(MAPF_DEV_C5)  // (development: the c5 shape only -- one wavefront per env, 5 x 5 windows)
+#define MAPF_FOR_LPE(X) X(64)
+#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
 #elif defined(MAPF_SMALL_SHAPES)  // (the checking build: groups of 4 and 8 lanes, windows up to 5 x 5)
 #define MAPF_FOR_LPE(X) X(4) X(8)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
@@ -81,6 +84,7 @@ struct mapf_engine {
     int mask_w = 32;
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
+    int many_dense = 0;  // the fused launch has more than two waves per SIMD: the 128-register build of k_step_many
     int three_wave = 0;  // k_step3 (state / observation / aux wave): specialised finite shapes with N = 4 or 8, not dense
     // step kernels compiled for exactly this configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), else null
     hipFunction_t jit_step = nullptr, jit_many = nullptr;
@@ -108,6 +112,7 @@ struct mapf_engine {
     int *d_err = nullptr;
     int *d_ep_acc = nullptr;
     uint32_t *d_stage_vals = nullptr;  // [B][2N] bounded draws of a staged background draw (Params::stage_vals)
+    uint64_t *d_jump_c = nullptr;   // [B][16][2] S_q * inc of every env's stream (Io::jump_c), rewritten whenever the streams are set
     uint64_t *d_vis_rng = nullptr;  // [B][6] visible stream state of envs whose placement slot is pending (Params::vis_rng)
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
@@ -241,6 +246,11 @@ hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream
 
 template <int LPE, int MW>
 hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
+    if constexpr (LPE < 32) {  // both register budgets, as for k_step
+        if (e->many_dense)
+            LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW, 4>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s,
+                           e->d_params, IO_HEAD_ARGS(io), T, obs_mode, pol);
+    }
     LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params,
                    IO_HEAD_ARGS(io), T, obs_mode, pol);
 }
@@ -365,7 +375,8 @@ void jit_specialize(mapf_engine *e) {
     const int wps = (lpe < 32 && e->dense) ? 4 : 0;
     const char *step_kernel = e->three_wave ? "k_step3" : "k_step";  // (three_wave implies wps == 0)
     const std::string step_expr = std::string("mapfjit::") + step_kernel + "<mapfjit::" + inst + tail_ + ", " + std::to_string(wps) + ">";
-    const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ">";
+    const int many_wps = (lpe < 32 && e->many_dense) ? 4 : 0;
+    const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ", " + std::to_string(many_wps) + ">";
     const std::string key = std::to_string(c.device) + "|" + step_expr;
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(key);
@@ -408,7 +419,7 @@ void jit_specialize(mapf_engine *e) {
         std::string src = "#include \"mapf_step.h\"\n#include \"mapf_kernels.inl\"\nnamespace mapfjit {\n";
         src += std::string("template __global__ void ") + step_kernel + "<" + inst + tail_ + ", " + std::to_string(wps) +
                ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);\n";
-        src += std::string("template __global__ void k_step_many<") + inst + tail_ +
+        src += std::string("template __global__ void k_step_many<") + inst + tail_ + ", " + std::to_string(many_wps) +
                ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail, const int, const int, const ManyPolicy);\n}\n";
         void *prog = nullptr;
         if (rt.create(&prog, src.c_str(), "mapf_jit.hip", 0, nullptr, nullptr) != 0) { e->jit_note = "hiprtcCreateProgram failed"; return; }
@@ -416,7 +427,7 @@ void jit_specialize(mapf_engine *e) {
         rt.add_name(prog, many_expr.c_str());
         const std::string o_arch = "--offload-arch=" + arch, o_i1 = "-I" + dir, o_i2 = "-I" + dir + "/../../include";
         const char *opts[] = {o_arch.c_str(), "-O3", "-std=c++17", o_i1.c_str(), o_i2.c_str(), "-mllvm", "-amdgpu-kernarg-preload-count=16",
-                              "-Wno-unused-value", "-DMAPF_NS=mapfjit"};
+                              "-Wno-unused-value", "-DMAPF_NS=mapfjit", "-DMAPF_NS_IS_JIT"};
         const int rc = rt.compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
         if (rc != 0) {
             size_t n = 0;
@@ -491,6 +502,12 @@ hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode
     switch (e->special) {
 #define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
     case ID:                                                                                                        \
+        if constexpr (LPE_ < 32) {                                                                                  \
+            if (e->many_dense)                                                                                      \
+                LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_), 4>), \
+                               dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
+                               obs_mode, pol);                                                                      \
+        }                                                                                                           \
         LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_)>), \
                        dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,   \
                        obs_mode, pol);
@@ -550,6 +567,26 @@ static int restore_visible_streams(mapf_engine *e) {
 // (conservative: the sampler skips the env for one step, the next step writes the real hint).
 static hipError_t force_may_finish(mapf_engine *e) {
     return hipMemset2D(e->d_scal + MAPF_CTR_MAY_FINISH, kScalInts * sizeof(int), 1, sizeof(int), (size_t)e->p.B);
+}
+
+// Io::jump_c: for every env the second half of the PCG64 jump-ahead, S_q * inc mod 2^128 for q = 1 .. 16, with
+// S_1 = 1, S_(q+1) = S_q * M + 1 (state_q = M^q * state + S_q * inc).  words = [B][6] stream words (inc in words 2, 3).
+static int upload_jump_table(mapf_engine *e, const uint64_t *words) {
+    const int B = e->p.B;
+    std::vector<uint64_t> tab((size_t)B * 32);
+    const unsigned __int128 M = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+    for (int b = 0; b < B; b++) {
+        const unsigned __int128 inc = ((unsigned __int128)words[(size_t)b * 6 + 2] << 64) | words[(size_t)b * 6 + 3];
+        unsigned __int128 S = 1;
+        for (int q = 1; q <= 16; q++) {
+            const unsigned __int128 c = S * inc;
+            tab[(size_t)b * 32 + 2 * (q - 1)] = (uint64_t)(c >> 64);
+            tab[(size_t)b * 32 + 2 * (q - 1) + 1] = (uint64_t)c;
+            S = S * M + 1;
+        }
+    }
+    HIP_TRY(e, hipMemcpy(e->d_jump_c, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return MAPF_OK;
 }
 
 // Host image of the agent state <-> the device planes (mapf_kernels.inl: agent_plane_off).
@@ -665,6 +702,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // 8192 x 16x16 x 4 agents 6.2 us at 16 lanes, 5.9 us at 8; 1024 x 32x32 x 8 agents 5.4 us at 64)
         while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < 1024) lpe <<= 1;
     }
+#if defined(MAPF_DEV_C5)
+    if (lpe != 64 || c.sensor_range > 2 || cte)
+        return fail(nullptr, MAPF_ERR_CONFIG, "this development build only holds 64-lane groups with windows up to 5 x 5");
+#endif
 #if defined(MAPF_DEV_C3) || defined(MAPF_SMALL_SHAPES)
     if ((lpe != 4 && lpe != 8) || c.sensor_range > 2 || cte)
         return fail(nullptr, MAPF_ERR_CONFIG, "this reduced build (development / checking) only holds groups of 4 and 8 lanes with windows up to 5 x 5");
@@ -704,6 +745,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         if (const char *f = getenv("MAPF_FORCE_DENSE")) e->dense = atoi(f) != 0;  // test knob: either build on any grid
         // k_step3 (state / observation / aux wave): the sliced-draw shapes, while a launch has at most three waves per
         // SIMD with three waves per workgroup (beyond that the two-wave kernel's 128-register build is the one that fits)
+        e->many_dense = (int64_t)e->blocks * (many_threads(lpe) / 64) > (int64_t)2 * 4 * cus;
+        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->many_dense = atoi(f) != 0;
         e->three_wave = sliced && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
         if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && atoi(f) != 0;  // test / A-B knob
         if (e->three_wave) e->dense = 0;
@@ -772,9 +815,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     }
     // k_step3's aux wave stages the info rows and counters of its envs in 2 KiB of its own (no cell map at these widths:
     // lds_map_off is free)
-    if (small_full && finite_sampled && lpe < 32) {
+    if (e->three_wave) {  // (only then: at 8 two-wave workgroups per CU -- 16 384 envs of the c3 shape -- these 2 KiB are the
+                          // difference between fitting the CU's 160 KiB of LDS and a second round of workgroups)
         e->lds_map_off = e->lds_bytes;
-        e->lds_bytes += 2048;
+        e->lds_bytes += 3072;  // + 1 KiB: the observation wave's goal-delta table (obs3_wave)
     }
     if (finite_sampled) {  // the sampler workgroups of a k_step launch have their own LDS layout
         const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
@@ -825,6 +869,8 @@ static int alloc_device_state(mapf_engine *e) {
     e->d_rng = streams_of(e->d_scal, B, N);
     e->d_n_free = free_counts_of(e->d_scal, B, N);
     HIP_TRY(e, hipMalloc(&e->d_vis_rng, (size_t)B * 6 * sizeof(uint64_t)));
+    HIP_TRY(e, hipMalloc(&e->d_jump_c, (size_t)B * 32 * sizeof(uint64_t)));
+    HIP_TRY(e, hipMemset(e->d_jump_c, 0, (size_t)B * 32 * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_stage_vals, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
     HIP_TRY(e, hipMemset(e->d_stage_vals, 0, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
     p.stage_vals = e->d_stage_vals;
@@ -865,7 +911,7 @@ int mapf_destroy(mapf_handle e) {
     // best effort: a failing free at teardown is reported through the return code, the handle goes away regardless
     DeviceScope scope(e->cfg.device);  // the caller's current device is restored when this returns (e.g. from __del__)
     hipError_t first = scope.status;
-    void *const bufs[] = {e->d_agents, e->d_scal, e->d_ring, e->d_rows, e->d_free_cells, e->d_free_rank, e->d_err, e->d_ep_acc, e->d_vis_rng, e->d_stage_vals, e->d_params, e->d_dbg};
+    void *const bufs[] = {e->d_jump_c, e->d_agents, e->d_scal, e->d_ring, e->d_rows, e->d_free_cells, e->d_free_rank, e->d_err, e->d_ep_acc, e->d_vis_rng, e->d_stage_vals, e->d_params, e->d_dbg};
     for (void *b : bufs) {
         const hipError_t rc = hipFree(b);
         if (first == hipSuccess) first = rc;
@@ -934,7 +980,7 @@ int mapf_set_rng_state(mapf_handle e, const uint64_t *rng_words) {
     HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(e->d_rng, rng_words, (size_t)e->p.B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(e, invalidate_slots(e));
-    return MAPF_OK;
+    return upload_jump_table(e, rng_words);
 }
 
 int mapf_get_state(mapf_handle e, mapf_state *out) {
@@ -1101,6 +1147,8 @@ int mapf_set_state(mapf_handle e, const mapf_state *in) {
     if (in->rng_words) {
         HIP_TRY(e, hipMemcpy(e->d_rng, in->rng_words, (size_t)B * 6 * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(e, invalidate_slots(e));
+        const int rc = upload_jump_table(e, in->rng_words);
+        if (rc != MAPF_OK) return rc;
     }
     HIP_TRY(e, force_may_finish(e));
     if (in->distance_ring && !ring_in_rec) {
@@ -1195,6 +1243,7 @@ static int step_impl(mapf_handle e, const int8_t *actions, const uint8_t *env_ma
     io.stage_vals = e->d_stage_vals;
     io.free_cells = e->d_free_cells;
     io.vis_rng = e->d_vis_rng;
+    io.jump_c = e->d_jump_c;
     ON_DEVICE(e);
     LAUNCH_TRY(e, dispatch(KIND_STEP, e, io, (hipStream_t)stream));
     return MAPF_OK;

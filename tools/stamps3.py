@@ -56,7 +56,7 @@ for k in order:
 print(f"  workgroup end (last of the three)  median {np.median(end):7.0f}  p95 {np.percentile(end, 95):7.0f}   slowest workgroup {np.median(end.max(axis=1)):7.0f}")
 kind = full[:, :, 23]
 if (kind > 0).any():
-    print(f"  state waves running a draw slice per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
+    print(f"  state waves running a draw slice (after B1) per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
     for k in range(1, 8):
         m = kind == k
         if m.any():
