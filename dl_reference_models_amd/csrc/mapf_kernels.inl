@@ -721,6 +721,18 @@ __device__ __forceinline__ void load_lane(const uint2 *hot, uint32_t bn8, size_t
     lane_unpack(r, is_agent, st);
 }
 
+// the hot plane alone (the single-agent env keeps no lock history: it never touches planes 1-3)
+__device__ __forceinline__ uint32_t load_lane_hot(const uint2 *hot, size_t idx, bool is_agent, Lane &st) {
+    const uint2 h = hot[idx];
+    st.pos = is_agent ? (h.x & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.goal = is_agent ? (h.x >> 16) : (uint32_t)kIdleGoal;
+    st.start = is_agent ? (h.y & 0xFFFFu) : (uint32_t)kIdleCell;
+    st.flags = is_agent ? ((h.y >> 16) & 0xFFu) : 0u;
+    st.moved = st.failed = st.progress = 0ull;
+    st.dist = make_uint4(0, 0, 0, 0);
+    return is_agent ? (h.y >> 24) : 0u;  // pass bits
+}
+
 // 16-byte state store (plain: write-through and nontemporal variants were measured and are slower)
 __device__ __forceinline__ void store_state16(void *dst, const uint4 v) { *reinterpret_cast<uint4 *>(dst) = v; }
 
@@ -3912,7 +3924,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     const int row_len = io.H * io.W + 5 * N;
     load_rows_to_lds<LPE>(io.grid_rows, io.H, lrows, lane, env0, ngroups);
     Lane st;
-    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
+    load_lane_hot(io.agents, (size_t)env * N + min(a, N - 1), is_agent, st);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
     if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
@@ -3929,7 +3941,8 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     }
     if (do_reset) {
         if (is_agent)
-            store_lane(io.agents, io.bn8, (size_t)env * N + a, st, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
+            store_lane_hot(io.agents, (size_t)env * N + a, st,
+                           agent_pass_bits(lrows + grp * (io.H + 2 * kRowPad) + kRowPad, st.pos, io.col_pad, io.W));
         if (a == 0) {
             int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
             sp[0] = make_int4(0, 0, 0, 0);  // step_count, -, _episode_blocking_count, -
@@ -3941,15 +3954,25 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
 // part of every env's observation row (the obstacle floats of the whole grid: most of this env's work, and
 // independent of the step) while wave 0 resolves the moves, then adds agents, goals and the joint mask once wave 0
 // has published the new positions (B1) and streams the rows out.  kCteW* = flag bits of the published entries.
+// Round 3: wave 0 waits for the hot plane and the actions only (8 + 1 bytes per agent; this env keeps no lock history),
+// takes "inside the grid and not an obstacle" from the agent's pass bits instead of the rows (no B0) and, in groups of 4
+// or 8 lanes, resolves the moves by DPP + swizzle (resolve_moves_dpp) instead of through a table in LDS.
+// T > 1 (mapf_cte_step_many): the same two waves run T steps in one launch -- positions stay in registers, the obstacle
+// floats are written ONCE (after a row has left, the 2N cells the overlay touched are set back to 0: agents and goals
+// only ever stand on free cells), per step only the actions are read and the outputs written.
 constexpr uint32_t kCteWAgent = 1u, kCteWSelShift = 1u, kCteWReset = 8u;
-template <int LPE>
-__global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp, const CteIo io) {
+struct CteMany {
+    int T;         // steps in this launch (1 = mapf_cte_step)
+    int obs_mode;  // fused launches: 0 no observation, 1 after the last step only, 2 every step ([T][B][row])
+};
+template <int LPE, bool FUSED>
+__global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp, const CteIo io, const CteMany many) {
     const Params &p = *pp;
     constexpr int G = 64 / LPE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint64_t *lrows = reinterpret_cast<uint64_t *>(lds_raw);
     uint4 *tab = reinterpret_cast<uint4 *>(lds_raw + io.lds_tab_off);
-    uint4 *otab = tab + 64;
+    uint4 *otab = tab + 64;  // two copies: consecutive steps of a fused launch alternate (the state wave may be a step ahead)
     float *stage = reinterpret_cast<float *>(lds_raw + io.lds_stage_off);
     int16_t *scratch = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch_off);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -3959,147 +3982,198 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
     const int row_len = H * W + 5 * N;
+    const int T = FUSED ? many.T : 1;
+    constexpr bool fused = FUSED;
+    const size_t BN = (size_t)io.B * N;
     uint4 *tabg = tab + grp * LPE;
     const uint64_t *myrows = lrows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = stage + (size_t)grp * row_len;
-    const bool want_obs = io.obs || io.final_obs;
-    Io fio;
-    fio.obs = io.obs;
-    fio.final_obs = io.final_obs;
+    // the observation tensor of step t (nullptr: this step produces none)
+    auto obs_of = [&](int t) -> float * {
+        if (!fused) return io.obs;
+        return many.obs_mode == 2 ? io.obs + (size_t)t * io.B * row_len : ((many.obs_mode == 1 && t == T - 1) ? io.obs : nullptr);
+    };
 
     if (wv == 1) {
         load_rows_to_lds<LPE>(io.grid_rows, H, lrows, lane, env0, ngroups);
-        wg_sync();  // B0: rows visible to the state wave
-        if (!want_obs) return;
-        cte_fill_grid<LPE>(io, myrows, srow, env_ok, a);
-        wg_sync();  // B1: positions after the move are published
-        const uint4 ent = otab[lane];
-        cte_overlay<LPE>(io, srow, (ent.z & kCteWAgent) != 0, a, ent.x, ent.y);
-        flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, (int)((ent.z >> kCteWSelShift) & 3u), row_len);
-        if (__any((ent.z & kCteWReset) != 0)) wg_sync();  // B2: the state wave re-uses the staging rows for the reset
+        wave_lds_sync();
+        const bool any_obs = fused ? many.obs_mode != 0 : (io.obs || io.final_obs);
+        if (any_obs) cte_fill_grid<LPE>(io, myrows, srow, env_ok, a);
+        for (int t = 0; t < T; t++) {
+            Io fio;
+            fio.obs = obs_of(t);
+            fio.final_obs = fused ? nullptr : io.final_obs;
+            wg_sync();  // B1: rows in LDS (first step) / positions after the move are published
+            if (!(fio.obs || fio.final_obs)) continue;
+            const uint4 ent = (otab + (t & 1) * 64)[lane];
+            const bool ag = (ent.z & kCteWAgent) != 0;
+            cte_overlay<LPE>(io, srow, ag, a, ent.x, ent.y);
+            flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, (int)((ent.z >> kCteWSelShift) & 3u), row_len);
+            const bool any_reset = __any((ent.z & kCteWReset) != 0);
+            if (fused) {  // put the touched cells back (free cells: 0) for the next step's overlay
+                wave_lds_sync();
+                if (ag) {
+                    srow[(ent.y >> 8) * W + (ent.y & 255u)] = 0.0f;
+                    srow[(ent.x >> 8) * W + (ent.x & 255u)] = 0.0f;
+                }
+                wave_lds_sync();
+            }
+            if (any_reset) wg_sync();  // B2: the state wave re-uses the staging rows for the reset observation
+            if (any_reset && fused) wg_sync();  // B3: ... and is done with them (it cleans up after itself)
+        }
         return;
     }
 
+    const size_t idx = (size_t)env * N + min(a, N - 1);
     Lane st;
-    load_lane(io.agents, io.bn8, (size_t)env * N + min(a, N - 1), is_agent, st);
+    uint32_t pass = load_lane_hot(io.agents, idx, is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
-    int act = is_agent ? (int)io.actions[(size_t)env * N + a] : 0;
-    wg_sync();  // B0
+    int step_count = sc0.x, blocking_total = sc0.z;
 
-    // invalid action: get_next_position raises mid-loop (SA-env:262, :401-403); agents before it were processed
-    const bool bad = is_agent && (act < 0 || act > 4);
-    const uint64_t badm = gballot<LPE>(bad, lane);
-    const bool errored = badm != 0;
-    const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
-    const bool live = is_agent && a < n_live;
-    if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
-    if (!live) act = 0;
-    int step_count = sc0.x + 1;  // SA-env:247
+    // (the actions of step t + 1 are requested while step t is computed: in a fused launch that load's latency would
+    //  otherwise open every step)
+    int act_next = (int)io.actions[(size_t)env * N + min(a, N - 1)];
+    for (int t = 0; t < T; t++) {
+        float *obs_t = obs_of(t);
+        const bool want_obs = fused ? obs_t != nullptr : (io.obs || io.final_obs);
+        int act = is_agent ? act_next : 0;
+        if (t + 1 < T) act_next = (int)io.actions[(size_t)(t + 1) * BN + (size_t)env * N + min(a, N - 1)];
+        // invalid action: get_next_position raises mid-loop (SA-env:262, :401-403); agents before it were processed
+        const bool bad = is_agent && (act < 0 || act > 4);
+        const uint64_t badm = gballot<LPE>(bad, lane);
+        const bool errored = badm != 0;
+        const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+        const bool live = is_agent && a < n_live;
+        if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
+        if (!live) act = 0;
+        const int step_now = step_count + 1;  // SA-env:247
 
-    // move (SA-env:259-274): the same sequential rule as the multi-agent env
-    const uint32_t old = st.pos;
-    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0), dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
-    const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
-    const uint64_t trow = live ? myrows[tr] : ~0ull;
-    const bool col_ok = io.col_pad != 0 || (tc >= 0 && tc < W);
-    const bool want = live && act != 0 && col_ok && !((trow >> ((tc + io.col_pad) & 63)) & 1ull);
-    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
-    const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
-    uint32_t cur = old;
-    if (__any(want)) cur = resolve_moves<KRuntime, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
-    const bool moved = cur != old;
+        // move (SA-env:259-274): the same sequential rule as the multi-agent env; the target's passability is the pass bit
+        const uint32_t old = st.pos;
+        const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0), dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+        const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
+        const bool want = live && act != 0 && ((pass >> ((act - 1) & 3)) & 1u) != 0;
+        const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+        const uint32_t intended1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
+        uint32_t cur = old;
+        if (__any(want)) {
+            if constexpr (LPE <= 8) cur = resolve_moves_dpp<LPE>(a, old, tgt);
+            else cur = resolve_moves<KRuntime, LPE>(p, reinterpret_cast<uint2 *>(tabg), lane, a, old, tgt);
+        }
+        const bool moved = cur != old;
 
-    // goal bookkeeping (SA-env:281-286)
-    bool reached_once = (st.flags & kFlagReached) != 0;
-    const bool on_goal = live && cur == st.goal;
-    const bool first = on_goal && !reached_once;
-    reached_once = reached_once || first;
-    const int k_first = __popcll(gballot<LPE>(first, lane));
+        // goal bookkeeping (SA-env:281-286)
+        bool reached_once = (st.flags & kFlagReached) != 0;
+        const bool on_goal = live && cur == st.goal;
+        const bool first = on_goal && !reached_once;
+        reached_once = reached_once || first;
+        const int k_first = __popcll(gballot<LPE>(first, lane));
+        const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
+        int term = 0, trunc = 0;
+        if (n_on_goal == N) term = 1;
+        else if (step_now >= io.steps_per_episode) term = trunc = 1;
+        const bool done = env_ok && !errored && (term | trunc);
+        const bool do_reset = done && (fused || io.auto_reset);
 
-    // all-pairs pass: intent blocking (SA-env:303-316) and coincidences (SA-env:296-300)
-    {
-        uint4 ent;
-        ent.x = old | (cur << 16);
-        ent.y = 0;
-        ent.z = (is_agent && !reached_once) ? intended1 : 0xFFFFFFFFu;
-        ent.w = 0u;
-        tabg[a] = ent;
-    }
-    wave_lds_sync();
-    bool blocks = false;
-    int same = 0;
-    const uint32_t mycell1 = cur + 0x0101u;
-    for (int j = 0; j < N; j++) {
-        const uint4 e = tabg[j];
-        blocks |= e.z == mycell1;
-        same += ((e.x >> 16) == cur) ? 1 : 0;
-    }
-    wave_lds_sync();
-    const bool blocking = is_agent && reached_once && !moved && blocks;
-    const int m_block = __popcll(gballot<LPE>(blocking, lane));
-    const int q_move = __popcll(gballot<LPE>(is_agent && reached_once && moved, lane));  // SA-env:320-325
-    int coll2 = is_agent ? same - 1 : 0;  // each coinciding pair is seen from both sides
-    for (int o = LPE / 2; o > 0; o >>= 1) coll2 += __shfl_xor(coll2, o, LPE);
-    const int n_on_goal = __popcll(gballot<LPE>(on_goal, lane));
-
-    // reward in float64, in the reference's order of additions (SA-env:253-346)
-    double reward = 0.5 * (double)k_first - (double)(coll2 / 2);
-    for (int i = 0; i < N; i++) if (i < m_block) reward += io.blocking_penalty;
-    for (int i = 0; i < N; i++) if (i < q_move) reward += io.move_after_goal_penalty;
-    int term = 0, trunc = 0;
-    if (n_on_goal == N) {
-        reward += (double)N;
-        term = 1;
-    } else if (step_count >= io.steps_per_episode) {
-        for (int i = 0; i < N; i++) if (i < N - n_on_goal) reward -= 1.0;
-        term = 1;
-        trunc = 1;
-    }
-    const int blocking_total = sc0.z + m_block;
-    const int reached_total = __popcll(gballot<LPE>(is_agent && reached_once, lane));
-    const bool done = env_ok && !errored && (term | trunc);
-    const bool do_reset = done && io.auto_reset;
-
-    // observation after ALL moves (SA-env:288-293): hand the new positions to the observation wave
-    st.pos = cur;
-    st.flags = reached_once ? kFlagReached : 0;
-    if (want_obs) {
-        const int sel = (!env_ok || errored) ? 2 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2));
-        otab[lane] = make_uint4(cur, st.goal, (is_agent ? kCteWAgent : 0u) | ((uint32_t)sel << kCteWSelShift) |
-                                                 (do_reset ? kCteWReset : 0u), 0u);
+        // observation after ALL moves (SA-env:288-293): hand the new positions to the observation wave
+        {
+            const int sel = (!env_ok || errored) ? 2 : (fused ? 0 : (do_reset ? (io.final_obs ? 1 : 2) : (io.obs ? 0 : 2)));
+            // (fused launches: a step that ends an episode shows the reset observation -- built below, after B2 -- so its
+            //  terminal row goes nowhere)
+            const int sel_f = (fused && do_reset) ? 2 : sel;
+            (otab + (t & 1) * 64)[lane] = make_uint4(cur, st.goal, (is_agent ? kCteWAgent : 0u) | ((uint32_t)sel_f << kCteWSelShift) |
+                                                                      ((do_reset && want_obs) ? kCteWReset : 0u), 0u);
+        }
         wg_sync();  // B1
-    }
-    if (env_ok && !errored && a == 0) {
-        if (io.reward) io.reward[env] = reward;
-        if (io.terminated) io.terminated[env] = (uint8_t)term;
-        if (io.truncated) io.truncated[env] = (uint8_t)trunc;
-        if (io.info) {
-            float4 v = make_float4((float)m_block, (float)k_first, (float)reached_total, (float)blocking_total);
-            *reinterpret_cast<float4 *>(io.info + (size_t)env * 4) = v;
-        }
-    }
-    int blocking_keep = errored ? sc0.z : blocking_total;  // the exception fires before the penalties are booked
 
-    if (__any(do_reset)) {
-        if (want_obs) wg_sync();  // B2: the observation wave is done with the staging rows
-        else wave_lds_sync();
-        if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
-            cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
-        if (do_reset) {
-            st.pos = st.start;
-            st.flags = 0;
-            step_count = 0;
-            blocking_keep = 0;
+        // all-pairs pass: intent blocking (SA-env:303-316) and coincidences (SA-env:296-300)
+        {
+            uint4 ent;
+            ent.x = old | (cur << 16);
+            ent.y = 0;
+            ent.z = (is_agent && !reached_once) ? intended1 : 0xFFFFFFFFu;
+            ent.w = 0u;
+            tabg[a] = ent;
         }
-        if (io.obs) {
-            cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, st.pos, st.goal);
-            flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
+        wave_lds_sync();
+        bool blocks = false;
+        int same = 0;
+        const uint32_t mycell1 = cur + 0x0101u;
+        for (int j = 0; j < N; j++) {
+            const uint4 e = tabg[j];
+            blocks |= e.z == mycell1;
+            same += ((e.x >> 16) == cur) ? 1 : 0;
         }
+        wave_lds_sync();
+        const bool blocking = is_agent && reached_once && !moved && blocks;
+        const int m_block = __popcll(gballot<LPE>(blocking, lane));
+        const int q_move = __popcll(gballot<LPE>(is_agent && reached_once && moved, lane));  // SA-env:320-325
+        int coll2 = is_agent ? same - 1 : 0;  // each coinciding pair is seen from both sides
+        for (int o = LPE / 2; o > 0; o >>= 1) coll2 += __shfl_xor(coll2, o, LPE);
+
+        // reward in float64, in the reference's order of additions (SA-env:253-346)
+        double reward = 0.5 * (double)k_first - (double)(coll2 / 2);
+        for (int i = 0; i < N; i++) if (i < m_block) reward += io.blocking_penalty;
+        for (int i = 0; i < N; i++) if (i < q_move) reward += io.move_after_goal_penalty;
+        if (term && !trunc) {
+            reward += (double)N;
+        } else if (trunc) {
+            for (int i = 0; i < N; i++) if (i < N - n_on_goal) reward -= 1.0;
+        }
+        const int reached_total = __popcll(gballot<LPE>(is_agent && reached_once, lane));
+        if (!errored) blocking_total += m_block;  // (the exception fires before the penalties are booked)
+        if (env_ok && !errored && a == 0) {
+            const size_t o = (size_t)t * io.B + env;
+            if (io.reward) io.reward[o] = reward;
+            if (io.terminated) io.terminated[o] = (uint8_t)term;
+            if (io.truncated) io.truncated[o] = (uint8_t)trunc;
+            if (io.info) {
+                float4 v = make_float4((float)m_block, (float)k_first, (float)reached_total, (float)blocking_total);
+                *reinterpret_cast<float4 *>(io.info + o * 4) = v;
+            }
+        }
+        st.pos = cur;
+        st.flags = reached_once ? kFlagReached : 0;
+        step_count = step_now;  // (also when the ValueError fires: SA-env:247 increments first)
+
+        if (__any(do_reset)) {
+            if (want_obs) wg_sync();  // B2: the observation wave is done with the staging rows
+            else wave_lds_sync();
+            if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
+                cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
+            if (do_reset) {
+                st.pos = st.start;
+                st.flags = 0;
+                step_count = 0;
+                blocking_total = 0;
+            }
+            if (fused ? obs_t != nullptr : io.obs != nullptr) {
+                Io fio;
+                fio.obs = obs_t;
+                fio.final_obs = nullptr;
+                if (fused) {  // the obstacle floats are in place: only the overlay, and its clean-up afterwards
+                    cte_overlay<LPE>(io, srow, is_agent && do_reset, a, st.pos, st.goal);
+                    flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
+                    wave_lds_sync();
+                    if (is_agent && do_reset) {
+                        srow[(st.goal >> 8) * W + (st.goal & 255u)] = 0.0f;
+                        srow[(st.pos >> 8) * W + (st.pos & 255u)] = 0.0f;
+                    }
+                    wave_lds_sync();
+                } else {
+                    cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, st.pos, st.goal);
+                    flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
+                }
+            }
+            if (fused && want_obs) wg_sync();  // B3
+        }
+        // pass bits of the cell the agent stands on now (the rows are in LDS since the first B1)
+        pass = is_agent ? agent_pass_bits(myrows, st.pos, io.col_pad, W) : 0u;
     }
-    if (is_agent) store_lane(io.agents, io.bn8, (size_t)env * N + a, st, myrows, io.col_pad, io.W);
+    if (is_agent) store_lane_hot(io.agents, (size_t)env * N + a, st, pass);
     if (env_ok && a == 0) {
         int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
-        sp[0] = make_int4(step_count, 0, blocking_keep, 0);
+        sp[0] = make_int4(step_count, 0, blocking_total, 0);
     }
 }
 
@@ -4111,7 +4185,7 @@ constexpr uint32_t kFlagsHeadline = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_A
                                     MAPF_FLAG_BLOCKING_PRESSURE | MAPF_FLAG_LOCK_METRICS;  // L = 33
 constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG_BLOCKING_PRESSURE |
                                       MAPF_FLAG_LOCK_METRICS;  // the reference's default obs, L = 28
-#if defined(MAPF_DEV_C3)  // development builds (mapf_step.hip): the headline shape only
+#if defined(MAPF_DEV_C3) || defined(MAPF_DEV_CTE)  // development builds (mapf_step.hip): the headline shape only
 #define MAPF_SPECIALIZATIONS(X) X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)
 #elif defined(MAPF_DEV_C5)
 #define MAPF_SPECIALIZATIONS(X) X(3, 64, 2, (kFlagsHeadline | MAPF_FLAG_LIFELONG), 8, 16, 2, 1, 64)
@@ -4134,7 +4208,7 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
 // The headline kernel is instantiated HERE, ahead of everything the host dispatchers instantiate: it then leads the code
 // object.  (The same kernel measured 1.5-4 % slower from deeper inside the library's code object than from a small one,
 // DESIGN.md 4 "Run-time specialisation" and 5b; where it sits is the one difference.)
-#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5)
+#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5) && !defined(MAPF_DEV_CTE)
 template __global__ void k_step3<KFixed<8, 2, kFlagsHeadline, 8, 16, 2, 1>, 8, 32, 0>(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);
 #endif
 

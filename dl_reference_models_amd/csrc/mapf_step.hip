@@ -54,6 +54,9 @@
 #if defined(MAPF_DEV_C3)
 #define MAPF_FOR_LPE(X) X(8)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
+#elif defined(MAPF_DEV_CTE)  // (development: the single-agent env at 8 and 64 lanes per env)
+#define MAPF_FOR_LPE(X) X(8) X(64)
+#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
 #elif defined(MAPF_DEV_C5)  // (development: the c5 shape only -- one wavefront per env, 5 x 5 windows)
 #define MAPF_FOR_LPE(X) X(64)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
@@ -1345,10 +1348,11 @@ static CteIo make_cte_io(const mapf_engine *e) {
     return io;
 }
 
-static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s) {
+static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s, CteMany many = CteMany{1, 2}) {
 #define MAPF_CASE(L)                                                                                                 \
     case L:                                                                                                          \
-        if (step) LAUNCH_CHECKED((k_cte_step<L>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io);      \
+        if (step && many.T > 1) LAUNCH_CHECKED((k_cte_step<L, true>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io, many); \
+        if (step) LAUNCH_CHECKED((k_cte_step<L, false>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io, many); \
         LAUNCH_CHECKED((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
     switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
@@ -1389,6 +1393,30 @@ int mapf_cte_step(mapf_handle e, const int8_t *actions, float *obs, double *rewa
     io.auto_reset = auto_reset;
     ON_DEVICE(e);
     LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+int mapf_cte_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, double *reward,
+                       uint8_t *terminated, uint8_t *truncated, float *info, void *stream) {
+    if (!e || !e->cte) return fail(e, MAPF_ERR_STATE, "not a MAPF_FLAG_SINGLE_AGENT handle");
+    if (!actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
+    if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_cte_step_many");
+    CteIo io = make_cte_io(e);
+    io.actions = actions;
+    io.obs = obs;
+    io.reward = reward;
+    io.terminated = terminated;
+    io.truncated = truncated;
+    io.info = info;
+    io.auto_reset = 1;
+    ON_DEVICE(e);
+    if (T == 1) {  // (the single-step kernel shape: obs_mode 0 = no observation)
+        if (obs_mode == 0) io.obs = nullptr;
+        LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
+        return MAPF_OK;
+    }
+    LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream, CteMany{T, obs_mode}));
     return MAPF_OK;
 }
 

@@ -122,6 +122,31 @@ class VecSingleAgentReferenceModel:
         return {"obs": self._obs, "reward": self._reward, "terminated": self._terminated, "truncated": self._truncated,
                 "info": self._info, "final_obs": self._final_obs if fo is not None else None}
 
+    def step_many(self, actions: torch.Tensor, obs_mode: int = 1) -> dict:
+        """T fused steps in one launch (mapf_cte_step_many).  actions: int8 [T, B, N].  Returns fresh tensors: obs
+        ([B, row] for obs_mode 1, [T, B, row] for 2, None for 0), reward [T, B] float64, terminated / truncated [T, B],
+        info [T, B, 4].  Finished envs are reset inside the launch (their row of that step is the reset observation)."""
+        if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
+        T, B = int(actions.shape[0]), self.num_envs
+        if tuple(actions.shape) != (T, B, self.num_agents):
+            raise ValueError(f"actions must have shape (T, {B}, {self.num_agents})")
+        dev = self.device
+        obs = None
+        if obs_mode == 1:
+            obs = torch.empty((B, self.obs_len), dtype=torch.float32, device=dev)
+        elif obs_mode == 2:
+            obs = torch.empty((T, B, self.obs_len), dtype=torch.float32, device=dev)
+        out = {"obs": obs, "reward": torch.empty((T, B), dtype=torch.float64, device=dev),
+               "terminated": torch.empty((T, B), dtype=torch.uint8, device=dev),
+               "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev),
+               "info": torch.empty((T, B, 4), dtype=torch.float32, device=dev)}
+        self._check(self._lib.mapf_cte_step_many(
+            self._h, T, C.c_void_p(actions.data_ptr()), None if obs is None else C.c_void_p(obs.data_ptr()), int(obs_mode),
+            C.c_void_p(out["reward"].data_ptr()), C.c_void_p(out["terminated"].data_ptr()),
+            C.c_void_p(out["truncated"].data_ptr()), C.c_void_p(out["info"].data_ptr()), self._stream()))
+        return out
+
     def poll_error(self):
         env, agent, value = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
         rc = self._lib.mapf_poll_error(self._h, self._stream(), C.byref(env), C.byref(agent), C.byref(value))

@@ -261,6 +261,16 @@ int mapf_cte_reset(mapf_handle h, const uint8_t *env_mask /* device */, float *o
 int mapf_cte_step(mapf_handle h, const int8_t *actions, float *obs, double *reward, uint8_t *terminated,
                   uint8_t *truncated, float *info, float *final_obs, int32_t auto_reset, void *stream);
 
+/* T consecutive steps of the single-agent env in ONE launch for an action stream known up front (the CTE counterpart of
+ * mapf_step_many; the reference's loop is `for t: obs, r, term, trunc, info = env.step(a[t]); if term or trunc:
+ * env.reset()` around SA-env:246-363 / :222-244): positions stay in registers, the obstacle part of the full-grid
+ * observation row is written once per launch, per step only the actions are read and the outputs written.
+ *   actions device int8 [T][B][N];  obs_mode 0: no observation, 1: [B][H*W+5N] after the last step, 2: [T][B][H*W+5N];
+ *   reward [T][B] float64, terminated / truncated [T][B], info [T][B][4]; any may be NULL.
+ * Finished envs are reset inside the loop; the observation of a step that ended an episode is the reset observation. */
+int mapf_cte_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, double *reward,
+                       uint8_t *terminated, uint8_t *truncated, float *info, void *stream);
+
 /* observation of every agent from the CURRENT state, nothing is modified: what the reference returns when
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().
  * obs: device float32 [B][N][L]. */

@@ -336,3 +336,45 @@ def test_draw_in_the_gap_between_conservative_and_exact_lemire_test(which):
             _eq("rng", env.get_state()["rng_words"], np.stack([e.rng_words() for e in batch.envs]), t)
     if which == "background":
         assert saw_failed_stage, "the background draw never met the gap (kSlotStageFailed was never seen)"
+
+
+@pytest.mark.parametrize("n,B,H,W,stagger", [(8, 1024, 16, 16, True), (4, 512, 10, 12, True), (8, 130, 32, 32, False)])
+def test_hipgraph_replay_of_step_launches_equals_the_oracle(n, B, H, W, stagger):
+    """bench.py times hipGraph replays of K step launches (K = 100, a different action slice per launch).  The launches
+    of a graph depend on each other through the env state only, so this pins that a replayed graph is the same sequence
+    of steps as plain launches -- three replays of a 100-launch graph against 300 oracle steps, episode boundaries
+    staggered over the batch, last observation, state and generator words."""
+    env, cfg = _vec(n, B=B, H=H, W=W, steps_per_episode=23)
+    orc = OracleStepper(cfg["grid"], cfg, seeds=cfg["seeds"])
+    _eq("reset", env.reset().cpu().numpy(), orc.reset())
+    if stagger:
+        counts = np.arange(B) % 23
+        c = env.get_state()["counters"]
+        c[:, 0] = counts
+        env.set_state(counters=c)
+        orc.set_step_counts(counts)
+    K = 100
+    acts = np.random.default_rng(17).integers(0, 5, size=(K, B, n)).astype(np.int8)
+    dev_acts = torch.from_numpy(acts).to(env.device)
+    base, stride = dev_acts.data_ptr(), B * n
+    for t in range(2):  # code object resident, slots under way: plain launches before the capture
+        env.step_raw(base + t * stride, torch.cuda.current_stream(env.device).cuda_stream, 1)
+        orc.step(acts[t])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sp = torch.cuda.current_stream(env.device).cuda_stream
+        for t in range(K):
+            assert env.step_raw(base + t * stride, sp, 1) == 0
+    for rep in range(3):
+        g.replay()
+        for t in range(K):
+            ref = orc.step(acts[t])
+        torch.cuda.synchronize()
+        env.poll_error()
+        _eq("obs after replay", env._obs.cpu().numpy(), ref["obs"], rep)
+        _eq("rewards after replay", env._rewards.cpu().numpy(), ref["rewards"], rep)
+        st = env.get_state()
+        _eq("positions", st["positions"], orc.positions(), rep)
+        _eq("goals", st["goals"], orc.goals(), rep)
+        _eq("rng words", st["rng_words"], orc.rng_words(), rep)

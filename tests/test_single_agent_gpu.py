@@ -94,3 +94,38 @@ def test_cte_randomized_configuration_fuzz():
             for k in ("obs", "reward", "terminated", "truncated", "info"):
                 _eq(f"case {case} {cfg} {H}x{W} {k}", ra[k], rb[k], t)
         _eq(f"case {case} rng", a.rng_words(), b.rng_words())
+
+
+@pytest.mark.parametrize("shape", [(130, 16, 16, 4, 23, 0), (65, 9, 7, 5, 6, 0), (40, 32, 32, 8, 31, 64), (24, 12, 12, 3, 1, 8),
+                                   (20, 40, 37, 40, 17, 0)])
+def test_cte_fused_launch_equals_single_steps_of_the_oracle(shape):
+    """mapf_cte_step_many: T steps in one launch (positions in registers, the obstacle part of the observation row written
+    once, the touched cells put back after every row) against the oracle stepped T times with reset-on-done; every
+    observation mode, episode ends inside the launch (also episodes of ONE step), single steps in between."""
+    import torch
+
+    B, H, W, N, spe, lanes = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "steps_per_episode": spe}
+    grids = synth_grids(B, H, W, 0.2, N, base_seed=150_000)
+    seeds = list(range(B))
+    a = CteEngineStepper(grids, cfg, seeds=seeds, lanes_per_env=lanes)
+    b = CteOracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset obs", a.reset(), b.reset())
+    rng = np.random.default_rng(4)
+    for rep, (T, mode) in enumerate(((37, 2), (5, 1), (11, 0), (1, 2), (19, 2), (1, 0), (26, 1))):
+        acts = rng.integers(0, 5, size=(T, B, N)).astype(np.int8)
+        out = a.env.step_many(torch.from_numpy(acts).to(a.env.device), obs_mode=mode)
+        refs = [b.step(acts[t]) for t in range(T)]
+        for k in ("reward", "terminated", "truncated", "info"):
+            _eq(f"fused {k}", out[k].cpu().numpy(), np.stack([r[k] for r in refs]), rep)
+        if mode == 2:
+            _eq("fused obs", out["obs"].cpu().numpy(), np.stack([r["obs"] for r in refs]), rep)
+        elif mode == 1:
+            _eq("fused last obs", out["obs"].cpu().numpy(), refs[-1]["obs"], rep)
+        _eq("positions", a.positions(), b.positions(), rep)
+        _eq("rng", a.rng_words(), b.rng_words(), rep)
+        acts1 = rng.integers(0, 5, size=(B, N)).astype(np.int8)  # a single step between fused launches
+        ra, rb = a.step(acts1), b.step(acts1)
+        for k in ("obs", "reward", "terminated", "truncated", "info"):
+            _eq(f"single {k}", ra[k], rb[k], rep)
+    a.env.poll_error()

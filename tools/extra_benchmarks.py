@@ -107,13 +107,23 @@ def run_cte(b=8192, h=16, w=16, n=4, density=0.20, lanes=0):
     us = 1e6 * dt / (pool * 10)
     # algorithmic bytes per env-step: observation row written, agent records + env scalars read and written,
     # obstacle rows and actions read, reward / flags / info written
-    bytes_env = 4 * env.obs_len + 2 * 48 * n + 2 * 64 + 8 * h + n + 8 + 2 + 16
+    # (round 3: this env reads and writes the 8-byte hot plane only -- it keeps no lock history; rounds 1-2 counted 2 x 48 n)
+    bytes_env = 4 * env.obs_len + 2 * 8 * n + 2 * 64 + 8 * h + n + 8 + 2 + 16
+    out = {"workload": f"CTE single-agent env {b} x {h}x{w} x {n} agents (obs {env.obs_len} floats/env)",
+           "envs": b, "agents": n, "obs_floats": env.obs_len, "lanes_per_env": lanes,
+           "single_step_per_launch": {"env_steps_per_s": b * pool * 10 / dt, "agent_steps_per_s": b * n * pool * 10 / dt,
+                                      "us_per_step": us, "algorithmic_bytes_per_env_step": bytes_env,
+                                      "roofline_frac": bytes_env * b / (us * 1e-6) / 8e12}}
+    for mode, label in ((2, "fused_obs_every_step"), (1, "fused_obs_last_only")):  # mapf_cte_step_many, T = 100
+        f = lambda: env.step_many(acts, obs_mode=mode)
+        f(); f()
+        dtf = timed(f, 5)
+        usf = 1e6 * dtf / (pool * 5)
+        out[label] = {"T": pool, "us_per_step": usf, "env_steps_per_s": b * pool * 5 / dtf}
+        if mode == 2:
+            out[label]["roofline_frac"] = bytes_env * b / (usf * 1e-6) / 8e12
     env.poll_error()
-    print(json.dumps({"workload": f"CTE single-agent env {b} x {h}x{w} x {n} agents (obs {env.obs_len} floats/env)",
-                      "envs": b, "agents": n, "obs_floats": env.obs_len, "lanes_per_env": lanes,
-                      "single_step_per_launch": {"env_steps_per_s": b * pool * 10 / dt, "agent_steps_per_s": b * n * pool * 10 / dt,
-                                                 "us_per_step": us, "algorithmic_bytes_per_env_step": bytes_env,
-                                                 "roofline_frac": bytes_env * b / (us * 1e-6) / 8e12}}), flush=True)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
