@@ -71,6 +71,12 @@ def run(name, over=None, fused_T=100, p=None, tag=None, envs=None, stagger=False
         out[label] = {"T": fused_T, "agent_steps_per_s": b * n * fused_T * 5 / dt, "us_per_step": 1e6 * dt / (fused_T * 5)}
         if mode == 2:
             out[label]["roofline_frac"] = bytes_step / (dt / (fused_T * 5)) / 8e12
+            # what a fused launch really moves per env-step: actions in, the observation row and the per-step outputs
+            # out (rewards f32, info_agent 2 x u8 per agent; terminated, truncated, info_all 14 x f32 per env) -- state,
+            # rows and counters stay in registers / LDS for the T steps, so the 8(d) figure above overstates the traffic
+            fused_bytes = (n * (1 + 4 * env.obs_len + 4 + 2) + 2 + 4 * 14) * b
+            out[label]["bytes_moved_per_env_step"] = fused_bytes // b
+            out[label]["frac_of_8TBs_on_bytes_moved"] = fused_bytes / (dt / (fused_T * 5)) / 8e12
     if cfg.get("include_action_mask_in_obs", False):  # T fused steps with the in-kernel masked-random policy
         f = lambda: env.step_many_sampled(fused_T, seed=5)
         f(); f()
