@@ -701,9 +701,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // one staging row of H*W + 5N floats per env: widen the groups until a wave's rows fit 64 KiB of LDS
         while (lpe < 64 && (64 / lpe) * (c.height * c.width + 5 * c.num_agents) * 4 > 56 * 1024) lpe <<= 1;
         // the work of this env is the H*W observation row, which spreads over however many lanes the group has:
-        // widen until the launch has one two-wave workgroup per SIMD (measured with the two-wave kernel:
-        // 8192 x 16x16 x 4 agents 6.2 us at 16 lanes, 5.9 us at 8; 1024 x 32x32 x 8 agents 5.4 us at 64)
-        while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < 1024) lpe <<= 1;
+        // widen until the launch has one two-wave workgroup per SIMD; half of that is enough once a group has 32 lanes
+        // (round 3, us per step single / fused: 8192 x 16x16 x 4 agents 5.0 / 2.5 at 8 lanes, 5.2 / 5.0 at 16;
+        // 1024 x 32x32 x 8 agents 5.2 / 2.65 at 16, 4.5 / 2.8 at 32, 4.7 / 3.3 at 64)
+        while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < (lpe >= 16 ? 512 : 1024)) lpe <<= 1;
     }
 #if defined(MAPF_DEV_C5)
     if (lpe != 64 || c.sensor_range > 2 || cte)
