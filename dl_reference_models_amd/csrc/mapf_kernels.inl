@@ -1351,6 +1351,7 @@ struct PcgPre {  // fetched ahead by the caller (background sampler): stream sta
     uint4 ja, js;  // {hi.lo32, hi.hi32, lo.lo32, lo.hi32} as stored in kPcgJumpA / kPcgJumpS
     bool have_cq = false;  // sliced draw: `ja` is A_q of the ONE output this lane computes in this pass and `cq` the env's
     uint4 cq = {0, 0, 0, 0};  // S_q * inc from Io::jump_c (same word order): one 128-bit product per output instead of two
+    bool have_j = true;  // false: stream and count only (an inline reset whose caller holds the stream in registers)
 };
 // First half: the raw outputs (jump-ahead) and all bounded draws -> vals[4N - 1] in the group's scratch.  Returns
 // whether the lane-parallel draw stands (else: sequential restatement); then the stream after the draws is in
@@ -1406,7 +1407,7 @@ __device__ __forceinline__ bool draw_stage_a(const Params &p, int16_t *scr, int 
             st = add128(mul128(ja, s0), cq);
         } else if (q == a + 1 || qpass == 1) {
             U128 ja = {kPcgJumpA[q][0], kPcgJumpA[q][1]}, js = {kPcgJumpS[q][0], kPcgJumpS[q][1]};
-            if (pre.have && qpass != 1) {
+            if (pre.have && pre.have_j && qpass != 1) {
                 ja = U128{(uint64_t)pre.ja.x | ((uint64_t)pre.ja.y << 32), (uint64_t)pre.ja.z | ((uint64_t)pre.ja.w << 32)};
                 js = U128{(uint64_t)pre.js.x | ((uint64_t)pre.js.y << 32), (uint64_t)pre.js.z | ((uint64_t)pre.js.w << 32)};
             }
@@ -1560,55 +1561,97 @@ __device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *
         // NumPy writes them, 2N dependent iterations each (40 k cycles of one wave at N = 64, during which the other
         // 1 023 wait for the launch to end).  With one group per wave (N > 32) both are restated with short chains:
         if (LPE == 64) {
-            // ---- Floyd.  chosen_k = val_k unless val_k was chosen before, then j_k = pop - size + k.  Only a SUSPECT
-            //      k can hit: one whose value occurred at a smaller index, or lies in the j range (>= pop - size); any
-            //      other k finds chosen_i in {val_i != val_k, j_i > val_k} for all i < k.  Suspects are found with an
-            //      all-pairs pass whose iterations do not depend on each other, and only they (a handful: 2N^2 / F
-            //      expected) run the sequential test, in index order.
-            const int v0 = (int)vals[min(a, size - 1)], v1 = (int)vals[min(a + LPE, size - 1)];
-            const int j0 = (int)vals[size + min(a, size - 2)], j1 = (int)vals[size + min(a + LPE, size - 2)];
-            bool dup0 = false, dup1 = false;
-            for (int q = 0; q < size; q++) {
-                const int x = (int)gshfl<LPE>((uint32_t)(q < LPE ? v0 : v1), q & (LPE - 1));
-                dup0 |= q < a && x == v0;
-                dup1 |= q < a + LPE && x == v1;
+            // One group per wave, 66 .. 128 values, element k and k + 64 in lane k.  No loop over the elements:
+            //
+            // ---- Floyd.  chosen_k = j_k = base + k if val_k is in the set when its turn comes, else val_k.  A value v
+            //      is in the set at time k iff it was DRAWN before (val_s == v, s < k: whoever drew it first put it
+            //      there, unless it already was) or it is the j of an earlier element that collided (v = j_u, u < k,
+            //      element u took j_u); nothing else ever enters the set.  So
+            //          coll_k = dup_k | (u_k < k & coll[u_k]),   u_k = val_k - base,
+            //      with dup_k from equality masks built by ballots over the 12 value bits (cells of a 64 x 64 grid), and
+            //      the second term a chain through LOWER indices that only exists for values in the j range (2N / F of
+            //      them): iterated to its fixed point, one or two rounds of two ballots in practice.
+            const int base = pop - size;
+            const bool e1 = a + 64 < size;
+            const int v0 = (int)vals[min(a, size - 1)], v1 = (int)vals[min(a + 64, size - 1)];
+            const uint64_t below = (1ull << a) - 1ull, above = a == 63 ? 0ull : (~0ull << (a + 1));
+            uint64_t q00 = ~0ull, q10 = ~0ull, q11 = __ballot(e1);  // elements of set s equal to my v_x: q<x><s>
+#pragma unroll 1  // (rare path inside the step kernels: unrolled, the two loops are 12 KB of a 70 KB kernel and every step
+                  // of c5 pays 2 % for them in instruction-cache misses)
+            for (int b = 0; b < 12; b++) {
+                const bool x0 = (v0 >> b) & 1, x1 = (v1 >> b) & 1;
+                const uint64_t B0 = __ballot(x0), B1 = __ballot(x1);
+                q00 &= x0 ? B0 : ~B0;
+                q10 &= x1 ? B0 : ~B0;
+                q11 &= x1 ? B1 : ~B1;
             }
-            c0 = v0;
-            c1 = v1;
-            const bool sus0 = a < size && (dup0 || v0 >= pop - size);
-            const bool sus1 = a + LPE < size && (dup1 || v1 >= pop - size);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint64_t u = __ballot(h == 0 ? sus0 : sus1);
-                while (u) {
-                    const int t = (int)__builtin_ctzll(u), k = t + h * LPE;
-                    u &= u - 1;
-                    const int val = (int)gshfl<LPE>((uint32_t)(h == 0 ? v0 : v1), t);
-                    const bool hit = (a < k && c0 == val) || (a + LPE < k && c1 == val);
-                    const int chosen = __ballot(hit) != 0 ? pop - size + k : val;
-                    if (a == t) {
-                        if (h == 0) c0 = chosen;
-                        else c1 = chosen;
-                    }
-                }
+            const bool dup0 = (q00 & below) != 0, dup1 = e1 && (q10 != 0 || (q11 & below) != 0);
+            const int u0 = v0 - base, u1 = v1 - base;
+            const bool r0 = u0 >= 0 && u0 < a, r1 = e1 && u1 >= 0 && u1 < a + 64;
+            bool k0 = dup0, k1 = dup1;
+            for (int it = 0; it < size; it++) {  // (the chain is shorter than the list: the bound is structural)
+                const uint64_t C0 = __ballot(k0), C1 = __ballot(k1);
+                const bool n0 = dup0 || (r0 && ((C0 >> (u0 & 63)) & 1ull));
+                const bool n1 = dup1 || (r1 && (((u1 < 64 ? C0 : C1) >> (u1 & 63)) & 1ull));
+                const bool changed = n0 != k0 || n1 != k1;
+                k0 = n0;
+                k1 = n1;
+                if (!__any(changed)) break;
             }
-            // ---- tail shuffle: swap(out[i], out[j_i]) for i = size-1 .. 1.  Every lane follows its own two elements
-            //      through the swaps (position p: p == i -> j, p == j -> i); the swap indices come from a broadcast
-            //      that does not depend on the positions, so an iteration's chain is two compares and two selects.
-            //      (A group that is not drawing runs along on junk: only registers, and the stores are guarded.)
-            int p0 = a, p1 = a + LPE;
-            for (int i = size - 1; i >= 1; i--) {
-                const int t = size - 1 - i;
-                const int j = (int)gshfl<LPE>((uint32_t)(t < LPE ? j0 : j1), t & (LPE - 1));
-                const int n0 = p0 == i ? j : (p0 == j ? i : p0);
-                const int n1 = p1 == i ? j : (p1 == j ? i : p1);
-                p0 = n0;
-                p1 = n1;
+            c0 = k0 ? base + a : v0;
+            c1 = k1 ? base + a + 64 : v1;
+            // ---- tail shuffle: for i = size-1 .. 1: swap(idx[i], idx[J_i]), J_i <= i.  Position i is final after step i
+            //      and receives what position J_i holds then.  A position q <= i holds, before step i, what the NEXT
+            //      step after i aiming at q put there (the steps run downwards: that is the latest write), else its
+            //      original element; and what step x puts somewhere is what position x held before step x, i.e. what the
+            //      first step above x aiming at x put there -- up(x) -- and so on: a forest of pointers to higher
+            //      indices.  final[i] = orig[root(nx(i))], nx(i) = the next step above i with the same aim (or
+            //      orig[J_i] if there is none).  nx and up are lowest-set-bit queries on equality masks over the 7 bits
+            //      of J; the roots come from pointer doubling on a 128-byte table (<= 7 rounds, 2-4 in practice).
+            const bool s0 = a >= 1, s1 = e1;  // element i is a step (i = 0 is not: J_0 := 0)
+            const int J0 = s0 ? (int)vals[size + size - 1 - a] & 127 : 0;
+            const int J1 = s1 ? (int)vals[size + size - 1 - min(a + 64, size - 1)] & 127 : 0;
+            const uint64_t V0 = ~1ull, V1 = __ballot(s1);
+            uint64_t n00 = V0, n01 = V1, n11 = V1;  // steps of set s aiming where element x aims: n<x><s>
+            uint64_t w00 = V0, w01 = V1, w11 = V1;  // steps of set s aiming AT element x (index a / a + 64): w<x><s>
+#pragma unroll 1  // (rare path inside the step kernels: unrolled, the two loops are 12 KB of a 70 KB kernel and every step
+                  // of c5 pays 2 % for them in instruction-cache misses)
+            for (int b = 0; b < 7; b++) {
+                const bool y0 = (J0 >> b) & 1, y1 = (J1 >> b) & 1;
+                const uint64_t B0 = __ballot(y0), B1 = __ballot(y1);
+                const bool i0 = (a >> b) & 1, i1 = b == 6 ? true : i0;  // bits of my indices a and a + 64
+                n00 &= y0 ? B0 : ~B0;
+                n01 &= y0 ? B1 : ~B1;
+                n11 &= y1 ? B1 : ~B1;
+                w00 &= i0 ? B0 : ~B0;
+                w01 &= i0 ? B1 : ~B1;
+                w11 &= i1 ? B1 : ~B1;
             }
-            MAPF_CHK(p, !(ok && a < size) || (unsigned)p0 < (unsigned)size, 4, env, p0);
-            MAPF_CHK(p, !(ok && a + LPE < size) || (unsigned)p1 < (unsigned)size, 4, env, p1);
-            if (ok && a < size) out[p0 & (2 * LPE - 1)] = (int16_t)c0;
-            if (ok && a + LPE < size) out[p1 & (2 * LPE - 1)] = (int16_t)c1;
+            auto lowest = [&](uint64_t m0, uint64_t m1, int none) -> int {  // lowest step in (set 0 | set 1), else `none`
+                return m0 ? (int)__builtin_ctzll(m0) : (m1 ? 64 + (int)__builtin_ctzll(m1) : none);
+            };
+            const int nx0 = lowest(n00 & above, n01, -1), nx1 = lowest(0ull, n11 & above, -1);
+            int p0 = lowest(w00 & above, w01, a), p1 = lowest(0ull, w11 & above, a + 64);  // up(x), or x itself: a root
+            uint8_t *ptr = reinterpret_cast<uint8_t *>(raw);       // (the raw outputs were consumed by stage a)
+            int16_t *chosen = reinterpret_cast<int16_t *>(raw) + 64;  // [128] behind the 128 pointer bytes
+            chosen[a] = (int16_t)c0;
+            chosen[a + 64] = (int16_t)c1;
+            for (int it = 0; it < 8; it++) {
+                ptr[a] = (uint8_t)p0;
+                ptr[a + 64] = (uint8_t)p1;
+                wave_lds_sync();
+                const int t0 = ptr[p0], t1 = ptr[p1];
+                const bool changed = t0 != p0 || t1 != p1;
+                p0 = t0;
+                p1 = t1;
+                wave_lds_sync();
+                if (!__any(changed)) break;
+            }
+            const int g0 = nx0 >= 0 ? (int)ptr[nx0] : J0, g1 = nx1 >= 0 ? (int)ptr[nx1] : J1;
+            MAPF_CHK(p, !ok || (unsigned)g0 < (unsigned)size, 4, env, g0);
+            MAPF_CHK(p, !(ok && e1) || (unsigned)g1 < (unsigned)size, 4, env, g1);
+            if (ok) out[a] = chosen[g0];
+            if (ok && e1) out[a + 64] = chosen[g1];
         } else {
             for (int k = 0; k < size; k++) {
                 const int val = (int)vals[k], j = pop - size + k;
@@ -1638,9 +1681,10 @@ __device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *
 // both halves back to back (the inline reset)
 template <int LPE>
 __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, int16_t *scr, int lane, int a, int env,
-                                                             bool env_ok, bool do_reset, int N, const uint64_t *rng_src) {
+                                                             bool env_ok, bool do_reset, int N, const uint64_t *rng_src,
+                                                             const PcgPre &pre = PcgPre{false, {}, 0, {}, {}}) {
     int pop = 0;
-    const bool ok = draw_stage_a<LPE>(p, scr, lane, a, env, env_ok, do_reset, N, nullptr, PcgPre{false, {}, 0, {}, {}}, rng_src, pop);
+    const bool ok = draw_stage_a<LPE>(p, scr, lane, a, env, env_ok, do_reset, N, nullptr, pre, rng_src, pop);
     draw_stage_b<LPE>(p, env, scr, lane, a, ok, N, pop);
     return ok;
 }
@@ -1653,7 +1697,13 @@ template <class K, int LPE, int MW>
 __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, const uint64_t *lrows, uint4 *tab, float *stage,
                                              int16_t *scratch, int lane, int a, int grp, int env, bool env_ok,
                                              bool is_agent, bool do_reset, Lane &st, int *sc, bool want_obs, uint32_t &nsg,
-                                             bool obs_wave_barrier = false) {
+                                             bool obs_wave_barrier = false, uint32_t *wave_map = nullptr,
+                                             const bool have_stream = false, const Pcg &stream = Pcg{}, int stream_pop = 0) {
+    // wave_map: the wave's LDS cell map when the group IS the wave (64 lanes) and the kernel has one: the reset observation
+    // of 33 .. 64 agents then reads its windows from the map (25 reads) instead of walking all pairs (7.5 k cycles at N = 64).
+    // stream / stream_pop: the env's generator and free-cell count when the caller holds them in registers already
+    // (lifelong steps: loaded before the move phase, advanced by this step's respawns; else requested when the end of
+    // the episode was decided): the draw does not start with a round trip to memory.
     const int N = K::N(p);
 #ifdef MAPF_STAMPS  // (stamps build: slots 24..28 of the workgroup's row time an inline reset)
 #define MAPF_STAMP_RG(k)                                                                                   \
@@ -1680,7 +1730,14 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
             int16_t *hs = scratch + grp * p.scratch_i16;
             const int16_t *out = hs + sample_out_off_i16(N);
             MAPF_CHK(p, sample_out_off_i16(N) + 2 * N + 8 <= p.scratch_i16 && p.hash_cap + 2 * N <= p.scratch_i16, 10, env, p.scratch_i16);
-            const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, rng_src);
+            PcgPre pre{false, {}, 0, {}, {}};
+            if (have_stream) {  // (by value through the inlined call: a pointer to the caller's copy would pin it in scratch)
+                pre.have = true;
+                pre.have_j = false;
+                pre.g = stream;
+                pre.pop = stream_pop;
+            }
+            const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, env_ok, draw, N, rng_src, pre);
             MAPF_STAMP_RG(25);
             if (__any(draw && !sampled)) {  // F = 2N or a Lemire rejection: the sequential restatement
                 int16_t *outs = hs + p.hash_cap;
@@ -1759,11 +1816,26 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
     MAPF_STAMP_RG(27);
     if (want_obs) {
         uint4 *tabg = tab + grp * LPE;
-        tabg[a] = static_entry(st.pos, st.goal);
-        wave_lds_sync();
         PairOut po;
-        observe<K, LPE, MW, kObsEmit>(p, io, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, stage + (size_t)(grp * N + a) * K::L(p),
-                                   is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
+        if (LPE == 64 && wave_map) {
+            const int map_w = io.W + 2 * kRowPad;
+            clear_cell_maps<LPE>(io, wave_map, lane);  // (a step's fields are of no use once its observation has left)
+            wave_lds_sync();
+            if (is_agent && do_reset) {
+                MAPF_CHK(p, (unsigned)map_index(st.pos, map_w) < (unsigned)((io.H + 2 * kRowPad) * map_w) &&
+                                (unsigned)map_index(st.goal, map_w) < (unsigned)((io.H + 2 * kRowPad) * map_w), 7, env, st.pos);
+                atomicOr(&wave_map[map_index(st.pos, map_w)], (uint32_t)a + 1u);           // owner-new field
+                atomicOr(&wave_map[map_index(st.goal, map_w)], ((uint32_t)a + 1u) << 14);  // goal-owner field
+            }
+            wave_lds_sync();
+            observe<K, LPE, MW, kObsEmit, LPE == 64>(p, io, lrows + kRowPad, tabg, stage + (size_t)a * K::L(p), is_agent && do_reset, a,
+                                                    st.pos, st.goal, true, false, 0, po, wave_map);
+        } else {
+            tabg[a] = static_entry(st.pos, st.goal);
+            wave_lds_sync();
+            observe<K, LPE, MW, kObsEmit>(p, io, lrows + grp * (io.H + 2 * kRowPad) + kRowPad, tabg, stage + (size_t)(grp * N + a) * K::L(p),
+                                       is_agent && do_reset, a, st.pos, st.goal, true, false, 0, po);
+        }
         wave_lds_sync();
     }
     MAPF_STAMP_RG(28);
@@ -1828,7 +1900,7 @@ __global__ __launch_bounds__(64) void k_reset(const Params *__restrict__ pp, con
     wave_lds_sync();
 
     reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, do_reset, st, sc,
-                             io.obs != nullptr, nsg);
+                             io.obs != nullptr, nsg, false, (LPE == 64 && io.use_map) ? l.map : nullptr);
     if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, do_reset ? 0 : 2);
     if (do_reset) {
         if (is_agent)
@@ -2020,6 +2092,12 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     // ('unlikely': measured both ways -- laid out inline the episode-end blocks cost every wave more (B1 is reached
     // 80 cycles later, 5.5 -> 5.7 us synchronised, 6.2 -> 6.4 staggered) than the jumps to the far end of the kernel
     // cost the waves that take them)
+    // Lifelong steps hold the env's generator and free-cell count in registers since before the move phase (g_ll, advanced
+    // by the respawns below): an inline draw at the end of this body starts from them instead of a round trip to memory.
+    // They wait in LDS meanwhile (kept in registers they stretched g_ll's live range over the whole body: +3 % on
+    // every step for the sake of the rare one).
+    bool have_rs = false;
+    uint4 *rs_stash = l.xpose + 128;  // 64 bytes past the info / counter staging of the wave's envs
     if (__builtin_expect(__any(do_reset), 0)) {
         if (nsg_lazy && !deterministic && !lifelong)  // (A/B: the slot is only fetched when an env of the wave finishes)
             nsg = slots_of(io.scal, io.B)[(size_t)env * N + min(a, N - 1)];
@@ -2027,6 +2105,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (!deterministic && !lifelong) slot_ok = gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
         fast_reset = do_reset && !use_map && slot_ok && (obs_wave || !want_any_obs);
         slow_reset = do_reset && !fast_reset;
+        have_rs = LPE == 64 && lifelong && slow_reset && !slot_ok;  // (one group per wave: wave-uniform)
         subst = fast_reset && io.final_obs == nullptr;  // reset observation in place of the terminal one
         if (do_reset) sel = io.final_obs ? 1 : ((subst && io.obs) ? 0 : 2);
         if (subst) obs_w0 = (obs_w0 & ~kObsWPressure) | kObsWFinal;
@@ -2130,12 +2209,20 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
                 }
             }
             if (reassigned && a == 0 && env_ok) pcg_store(g, p.rng + (size_t)env * 6);
+            if (reassigned) g_ll = g;
             if (on_goal) {  // MA-env:547-556
                 reward += 0.5f;
                 grs = true;
                 completed = true;
                 reached = false;
                 on_goal = false;  // reached_goal[i] = False after the respawn
+            }
+        }
+        if (LPE == 64 && __builtin_expect(__any(have_rs), 0)) {
+            if (a == 0) {
+                rs_stash[0] = make_uint4((uint32_t)g_ll.shi, (uint32_t)(g_ll.shi >> 32), (uint32_t)g_ll.slo, (uint32_t)(g_ll.slo >> 32));
+                rs_stash[1] = make_uint4((uint32_t)g_ll.ihi, (uint32_t)(g_ll.ihi >> 32), (uint32_t)g_ll.ilo, (uint32_t)(g_ll.ilo >> 32));
+                rs_stash[2] = make_uint4(g_ll.has32, g_ll.uinteger, (uint32_t)F_ll, 0u);
             }
         }
     }
@@ -2458,8 +2545,18 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (__builtin_expect(__any(slow_reset), 0)) {
         if (slow_reset) sc[MAPF_CTR_EPISODES_DONE] += 1;
         wave_lds_sync();
+        Pcg g_rs = Pcg{};
+        int F_rs = 0;
+        if (LPE == 64 && have_rs) {
+            const uint4 s0 = rs_stash[0], s1 = rs_stash[1], s2 = rs_stash[2];
+            g_rs.shi = (uint64_t)s0.x | ((uint64_t)s0.y << 32); g_rs.slo = (uint64_t)s0.z | ((uint64_t)s0.w << 32);
+            g_rs.ihi = (uint64_t)s1.x | ((uint64_t)s1.y << 32); g_rs.ilo = (uint64_t)s1.z | ((uint64_t)s1.w << 32);
+            g_rs.has32 = s2.x; g_rs.uinteger = s2.y;
+            F_rs = (int)s2.z;
+        }
         reset_groups<K, LPE, MW>(p, io, l.rows, l.tab, l.stage, l.scratch, lane, a, grp, env, env_ok, is_agent, slow_reset,
-                                 st, sc, io.obs != nullptr, nsg, obs_wave);  // B2 inside: after the draw, before the observation
+                                 st, sc, io.obs != nullptr, nsg, obs_wave,  // B2 inside: after the draw, before the observation
+                                 (LPE == 64 && use_map) ? l.map : nullptr, have_rs, g_rs, F_rs);
         if (io.obs) flush_obs<K, LPE>(p, io, l.stage, lane, env0, ngroups, slow_reset ? 0 : 2);
     }
     return records_stored;
