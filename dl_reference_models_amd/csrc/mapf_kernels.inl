@@ -3863,6 +3863,30 @@ __global__ __launch_bounds__(many_threads(LPE), (WPS ? WPS : 1)) void k_step_man
     if (full || is_agent)
         store_lane(io.agents, io.bn8, (size_t)env * N + a, st, l.rows + grp * (io.H + 2 * kRowPad) + kRowPad, io.col_pad, io.W);
     if (env_ok && a == 0) store_scal(io.scal, env, sc);
+    // ---- tail: the NEXT placement of every env of the wave whose slot is empty (consumed by a reset of this launch, or
+    //      never drawn) is drawn here, once per launch, all groups of the wave side by side: the single-step kernels
+    //      spread that draw over the launches of an episode (slices, sampler workgroups); a fused launch has no
+    //      background, and without this every episode end of the next launch drew inline (staggered c3: 4.13 us per
+    //      step against 3.60 in phase).  Finite episodes only: there the env's stream is consumed by reset() alone, so
+    //      drawing ahead changes nothing the reference would see (Params::vis_rng keeps the visible stream, as for any
+    //      pre-drawn slot).  A slot that a single-step launch left half drawn (staged) is not touched.
+    if (!(K::flags(p) & (MAPF_FLAG_DETERMINISTIC | MAPF_FLAG_LIFELONG))) {
+        const bool need = env_ok && gballot<LPE>(is_agent && a == 0 && nsg == kSlotInvalid, lane) != 0;
+        if (__any(need)) {
+            int16_t *hs = l.scratch + grp * p.scratch_i16;
+            int pop = 0;
+            const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, env_ok, need, N, p.vis_rng, PcgPre{false, {}, 0, {}, {}}, p.rng, pop);
+            draw_stage_b<LPE>(p, env, hs, lane, a, ok, N, pop);
+            if (need && ok && is_agent) {
+                const int16_t *out = hs + sample_out_off_i16(N);
+                const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+                const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+                MAPF_CHK(p, (unsigned)out[a] < (unsigned)p.n_free[env] && (unsigned)out[N + a] < (unsigned)p.n_free[env], 6, env, out[a]);
+                const uint32_t cs = fc[min(max((int)out[a], 0), top)], cg = fc[min(max((int)out[N + a], 0), top)];
+                slots_of(io.scal, io.B)[(size_t)env * N + a] = cs | (cg << 16);
+            }
+        }
+    }
 }
 
 // ================================================================================================
