@@ -14,7 +14,7 @@ import torch
 
 from digest_util import TraceHasher
 from test_oracle_golden import REF_DIGEST, REF_SUMMARY
-from trace_util import EngineStepper, OracleStepper, _eq, synth_grids
+from trace_util import EngineStepper, OracleStepper, _eq, compare_steppers, synth_grids
 
 pytestmark = pytest.mark.gpu
 
@@ -378,3 +378,69 @@ def test_hipgraph_replay_of_step_launches_equals_the_oracle(n, B, H, W, stagger)
         _eq("positions", st["positions"], orc.positions(), rep)
         _eq("goals", st["goals"], orc.goals(), rep)
         _eq("rng words", st["rng_words"], orc.rng_words(), rep)
+
+
+# ---- 64-lane groups: Floyd's sampling + tail shuffle without a loop over the elements -----------------------------------
+@pytest.mark.parametrize("case", [
+    (24, 64, 64, 64, 0.20, 3, 40, {}),
+    (16, 12, 12, 64, 0.0, 2, 40, {}),      # F = 144, 2N = 128: almost every Floyd draw lies in the j range (collision chains)
+    (16, 12, 11, 64, 0.0, 1, 30, {}),      # F = 132, episodes of one step: a draw in every launch
+    (16, 9, 9, 33, 0.1, 2, 40, {}),        # 2N = 66 of F ~ 73: the second element set is almost empty
+    (20, 40, 37, 48, 0.15, 5, 60, {"lifelong_mapf": True}),  # lifelong: the inline draw starts from the stream held in LDS
+    (9, 30, 30, 40, 0.3, 4, 50, {"sensor_range": 3, "include_action_mask_in_obs": False}),
+    (12, 20, 20, 50, 0.1, 3, 40, {"force_pair_walk": True}),  # the all-pairs reset observation stays reachable
+])
+def test_wide_group_inline_draws_match_oracle(case):
+    """N = 33 .. 64 (one env per wave): rng.choice(F, 2N, replace=False) restated without a loop over the 2N elements
+    (equality masks by ballots over the value bits, collision chain and swap forest by pointer jumping; MA-env:267-282)
+    and the reset observation read off the LDS cell map, over many episode ends, also on populations barely larger than
+    the sample, where NumPy's Floyd collides in most iterations.  Engine vs oracle incl. generator words."""
+    B, H, W, N, dens, spe, T, extra = case
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "include_action_mask_in_obs": True, "steps_per_episode": spe}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, dens, N, base_seed=90_000)
+    acts = np.random.default_rng(5).integers(0, 5, size=(T, B, N)).astype(np.int8)
+    seeds = list(range(700, 700 + B))
+    eng = EngineStepper(grids, cfg, seeds=seeds)
+    compare_steppers(eng, OracleStepper(grids, cfg, seeds=seeds), acts)
+    eng.env.poll_error()
+
+
+# ---- fused launches: the tail pre-draw --------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(130, 32, 32, 8, 0.4, 50), (67, 16, 16, 4, 0.2, 5), (64, 10, 10, 8, 0.1, 1), (40, 12, 9, 16, 0.1, 13),
+                                   (20, 30, 30, 40, 0.2, 9)])
+def test_fused_launches_predraw_next_placement_and_stay_on_the_oracle(shape):
+    """k_step_many draws the next placement of every env with an empty slot at the end of the launch.  Fused launches of
+    several lengths against the ORACLE stepped one step at a time, phases staggered, single steps in between (slots drawn
+    by a fused tail are consumed by single-step launches; slices begun by single steps meet a fused launch), visible
+    generator words after every launch."""
+    import torch
+
+    B, H, W, N, dens, spe = shape
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "include_action_mask_in_obs": True, "steps_per_episode": spe}
+    grids = synth_grids(B, H, W, dens, N, base_seed=33_000)
+    seeds = list(range(900, 900 + B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    counts = np.arange(B) % spe
+    eng.set_step_counts(counts)
+    orc.set_step_counts(counts)
+    rng = np.random.default_rng(3)
+    for rep, T in enumerate((7, 50, 1, 130, 3, 64, 20)):
+        acts = rng.integers(0, 5, size=(T, B, N)).astype(np.int8)
+        out = eng.env.step_many(torch.from_numpy(acts).to(eng.env.device), obs_mode=2)
+        out = {k: v.cpu().numpy() for k, v in out.items()}
+        for t in range(T):
+            r = orc.step(acts[t])
+            for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+                _eq(f"fused {k} rep {rep}", out[k][t], r[k], t)
+        _eq("rng words", eng.rng_words(), orc.rng_words(), rep)
+        _eq("positions", eng.positions(), orc.positions(), rep)
+        _eq("goals", eng.goals(), orc.goals(), rep)
+        for t in range(int(rng.integers(0, 12))):
+            a1 = rng.integers(0, 5, size=(B, N)).astype(np.int8)
+            ra, rb = eng.step(a1), orc.step(a1)
+            for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+                _eq(f"single {k} rep {rep}", ra[k], rb[k], t)
+        _eq("rng words after singles", eng.rng_words(), orc.rng_words(), rep)
+    eng.env.poll_error()
