@@ -1560,8 +1560,9 @@ __device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *
         // Longer lists (N > 8: up to 128 values at N = 64).  Floyd's sampling and the tail shuffle are sequential as
         // NumPy writes them, 2N dependent iterations each (40 k cycles of one wave at N = 64, during which the other
         // 1 023 wait for the launch to end).  With one group per wave (N > 32) both are restated with short chains:
-        if (LPE == 64) {
-            // One group per wave, 66 .. 128 values, element k and k + 64 in lane k.  No loop over the elements:
+        if (LPE == 64 && size > 64) {
+            // One group per wave, 66 .. 128 values, element k and k + 64 in lane k (fewer values in a 64-lane group --
+            // lanes_per_env forced wider than the agents need -- take the loop below).  No loop over the elements:
             //
             // ---- Floyd.  chosen_k = j_k = base + k if val_k is in the set when its turn comes, else val_k.  A value v
             //      is in the set at time k iff it was DRAWN before (val_s == v, s < k: whoever drew it first put it
@@ -1687,6 +1688,15 @@ __device__ __forceinline__ bool sample_starts_goals_parallel(const Params &p, in
     const bool ok = draw_stage_a<LPE>(p, scr, lane, a, env, env_ok, do_reset, N, nullptr, pre, rng_src, pop);
     draw_stage_b<LPE>(p, env, scr, lane, a, ok, N, pop);
     return ok;
+}
+
+// zero the wave's cell maps (16-byte LDS stores; in k_step this runs under the latency of the state loads)
+template <int LPE>
+__device__ __forceinline__ void clear_cell_maps(const Io &io, uint32_t *map, int lane) {
+    constexpr int G = 64 / LPE;
+    const int n4 = (G * (io.H + 2 * kRowPad) * (io.W + 2 * kRowPad) + 3) >> 2;  // region is padded to 16 bytes
+    uint4 *m4 = reinterpret_cast<uint4 *>(map);
+    for (int k = lane; k < n4; k += 64) m4[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1839,15 +1849,6 @@ __device__ __forceinline__ void reset_groups(const Params &p, const Io &io, cons
         wave_lds_sync();
     }
     MAPF_STAMP_RG(28);
-}
-
-// zero the wave's cell maps (16-byte LDS stores; in k_step this runs under the latency of the state loads)
-template <int LPE>
-__device__ __forceinline__ void clear_cell_maps(const Io &io, uint32_t *map, int lane) {
-    constexpr int G = 64 / LPE;
-    const int n4 = (G * (io.H + 2 * kRowPad) * (io.W + 2 * kRowPad) + 3) >> 2;  // region is padded to 16 bytes
-    uint4 *m4 = reinterpret_cast<uint4 *>(map);
-    for (int k = lane; k < n4; k += 64) m4[k] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // LDS carve-up shared by the three kernels

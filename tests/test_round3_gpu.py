@@ -389,6 +389,8 @@ def test_hipgraph_replay_of_step_launches_equals_the_oracle(n, B, H, W, stagger)
     (20, 40, 37, 48, 0.15, 5, 60, {"lifelong_mapf": True}),  # lifelong: the inline draw starts from the stream held in LDS
     (9, 30, 30, 40, 0.3, 4, 50, {"sensor_range": 3, "include_action_mask_in_obs": False}),
     (12, 20, 20, 50, 0.1, 3, 40, {"force_pair_walk": True}),  # the all-pairs reset observation stays reachable
+    (8, 6, 7, 6, 0.1, 3, 40, {"lanes_per_env": 64}),          # a 64-lane group with 12 values: the loop formulation
+    (8, 5, 9, 10, 0.1, 4, 40, {"lanes_per_env": 64, "lifelong_mapf": True}),
 ])
 def test_wide_group_inline_draws_match_oracle(case):
     """N = 33 .. 64 (one env per wave): rng.choice(F, 2N, replace=False) restated without a loop over the 2N elements
@@ -397,11 +399,13 @@ def test_wide_group_inline_draws_match_oracle(case):
     the sample, where NumPy's Floyd collides in most iterations.  Engine vs oracle incl. generator words."""
     B, H, W, N, dens, spe, T, extra = case
     cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "include_action_mask_in_obs": True, "steps_per_episode": spe}
+    extra = dict(extra)
+    kw = {"lanes_per_env": extra.pop("lanes_per_env")} if "lanes_per_env" in extra else {}
     cfg.update(extra)
     grids = synth_grids(B, H, W, dens, N, base_seed=90_000)
     acts = np.random.default_rng(5).integers(0, 5, size=(T, B, N)).astype(np.int8)
     seeds = list(range(700, 700 + B))
-    eng = EngineStepper(grids, cfg, seeds=seeds)
+    eng = EngineStepper(grids, cfg, seeds=seeds, **kw)
     compare_steppers(eng, OracleStepper(grids, cfg, seeds=seeds), acts)
     eng.env.poll_error()
 

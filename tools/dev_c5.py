@@ -22,13 +22,16 @@ if what in ("parity", "all"):
         (20, 40, 37, 48, 0.15, 5, 60, {"lifelong_mapf": True}),
         (9, 30, 30, 40, 0.3, 4, 50, {"include_action_mask_in_obs": False}),
     ]
+    cases += [(8, 6, 7, 6, 0.1, 3, 40, {"lanes_per_env": 64}), (8, 5, 9, 10, 0.1, 4, 40, {"lanes_per_env": 64, "lifelong_mapf": True})]
     for (B, H, W, N, dens, spe, T, extra) in cases:
         cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": 2, "include_action_mask_in_obs": True, "steps_per_episode": spe}
+        extra = dict(extra)
+        kw = {"lanes_per_env": extra.pop("lanes_per_env")} if "lanes_per_env" in extra else {}
         cfg.update(extra)
         grids = synth_grids(B, H, W, dens, N, base_seed=90_000)
         acts = np.random.default_rng(5).integers(0, 5, size=(T, B, N)).astype(np.int8)
         seeds = list(range(700, 700 + B))
-        eng = EngineStepper(grids, cfg, seeds=seeds)
+        eng = EngineStepper(grids, cfg, seeds=seeds, **kw)
         compare_steppers(eng, OracleStepper(grids, cfg, seeds=seeds), acts)
         eng.env.poll_error()
         print("parity ok", (B, H, W, N, dens, spe, T, extra), flush=True)
