@@ -2127,9 +2127,6 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (obs_wave && !lifelong && !use_map) {  // finite episodes: goals are fixed, the observation only waited for the moves
         otabg[a] = obs_entry(false);
         wg_sync();  // B1
-#ifdef MAPF_K2_PRIO_STATE
-        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
-#endif
         MAPF_STAMP(19);  // (sub-stamp: finite mode, observation wave released)
     }
 
@@ -2297,9 +2294,6 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
     if (obs_wave && lifelong && !use_map) {  // respawned goals are part of the observation: publish after the goal logic
         otabg[a] = obs_entry(reassigned);
         wg_sync();  // B1
-#ifdef MAPF_K2_PRIO_STATE
-        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
-#endif
     }
     if (use_map) {
         // large N: every agent ORs its remaining fields into the env's cell map (owner-old went in before the move),
@@ -2317,9 +2311,6 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         if (obs_wave) {  // the observation wave reads its window from the map: release it when the map is complete
             otabg[a] = obs_entry(reassigned);
             wg_sync();  // B1
-#ifdef MAPF_K2_PRIO_STATE
-        __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_STATE);
-#endif
         } else {
             wave_lds_sync();
         }
@@ -2586,9 +2577,6 @@ __device__ __forceinline__ void obs_wave_step(const Params &p, const Io &io, con
     const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;
     float *srow = l.stage + (size_t)(grp * N + min(a, N - 1)) * K::L(p);
     if (!past_b1) wg_sync();  // B1
-#ifdef MAPF_K2_PRIO_OBS
-    if (!past_b1) __builtin_amdgcn_s_setprio(MAPF_K2_PRIO_OBS);
-#endif
     MAPF_STAMP_W1(11);
     const uint4 ent = otabg[a];
     const uint32_t w = ent.w;
