@@ -2746,8 +2746,8 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         const int qpass = __any(stage == 1) ? 1 : 0;
         pre.js = make_uint4(0, 0, 0, 0);
         pre.have_cq = true;  // one 128-bit product per output: A_q * state + (S_q * inc from the env's table)
-        pre.ja = d.ja[qpass == 1 ? 0 : 1];
-        pre.cq = d.cq[qpass == 1 ? 0 : 1];
+        pre.ja = qpass == 1 ? d.ja[0] : d.ja[1];  // (a select of values: indexed with a run-time value the request lives in
+        pre.cq = qpass == 1 ? d.cq[0] : d.cq[1];  //  scratch memory under the older clang of a host process's hiprtc)
         int pop_unused;
         const bool ok = draw_stage_a<LPE>(p, hs, lane, a, env, on, on, N, io.vis_rng, pre, p.rng, pop_unused, -1, 1,
                                           streams_of(io.scal, io.B, N), qpass, sv);

@@ -279,6 +279,11 @@ struct Hiprtc {
     int (*code)(void *, char *) = nullptr;
     int (*lowered)(void *, const char *, const char **) = nullptr;
     int (*destroy)(void **) = nullptr;
+    int (*version)(int *, int *) = nullptr;  // optional
+    std::string ver = "?";  // "major.minor" of the hiprtc the process resolved.  Under PyTorch that is the wheel's bundled
+                            // ROCm, not the toolkit this library was built with: on this image clang 20 (ROCm 7.0) against
+                            // clang 22 (7.2), which is the whole difference between a kernel compiled at creation and the
+                            // same kernel prebuilt ("Run-time specialisation")
     bool ok = false;
 };
 const Hiprtc &hiprtc_api() {
@@ -305,6 +310,9 @@ const Hiprtc &hiprtc_api() {
         sym(h.lowered, "hiprtcGetLoweredName");
         sym(h.destroy, "hiprtcDestroyProgram");
         h.ok = all;
+        h.version = reinterpret_cast<int (*)(int *, int *)>(dlsym(h.lib, "hiprtcVersion"));
+        int major = 0, minor = 0;
+        if (h.version && h.version(&major, &minor) == 0) h.ver = std::to_string(major) + "." + std::to_string(minor);
     });
     return h;
 }
@@ -397,7 +405,7 @@ void jit_specialize(mapf_engine *e) {
         if (!cdir.empty()) {
             uint64_t h = fnv1a(slurp(dir + "/mapf_kernels.inl"));
             h = fnv1a(slurp(dir + "/../../include/mapf_step.h"), h);
-            h = fnv1a(step_expr + "|" + many_expr + "|" + arch + "|O3 c++17 kernarg-preload-16 v2", h);
+            h = fnv1a(step_expr + "|" + many_expr + "|" + arch + "|O3 c++17 kernarg-preload-16 v2|hiprtc " + rt.ver, h);
             char name[40];
             snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
             cfile = cdir + name;
@@ -478,8 +486,9 @@ void jit_specialize(mapf_engine *e) {
     }
     e->jit_step = it->second.step;
     e->jit_many = it->second.many;
-    char note[128];
-    snprintf(note, sizeof note, it->second.from_disk ? "loaded from the on-disk cache in %.2f s: " : "compiled in %.1f s: ", it->second.seconds);
+    char note[160];
+    snprintf(note, sizeof note, it->second.from_disk ? "loaded from the on-disk cache in %.2f s (hiprtc %s): " : "compiled in %.1f s (hiprtc %s): ",
+             it->second.seconds, rt.ver.c_str());
     e->jit_note = note + step_expr;
 }
 
