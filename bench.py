@@ -414,13 +414,21 @@ def worker(args) -> int:
         # since its phase was set, the placements of the episodes ending in the window have been pre-drawn in the
         # background -- and a GPU that has been busy, instead of the start-up transient after the idle of the capture
         pre = args.pre_roll if args.pre_roll >= 0 else spe
-        run_steps(pre, plan(pre))
-        run_steps(args.warmup, pl_w)
-        fence()
-        ep0 = int(env.episode_sums()[L.ACC_EPISODES])
+        pl_p = plan(pre)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(stream)  # (torch creates the HIP event at its first record: not inside the timed region)
         ev1.record(stream)
+        ep_before = torch.zeros(L.NUM_EPISODE_ACC, dtype=torch.int64, device=device)
+        fence()
+        # Nothing but the fence stands between the warm-up launches and the timed region: the episode count before the
+        # region is taken ON THE DEVICE, behind the last warm-up launch (mapf_episode_stats_async), and read back after
+        # the region.  (Round 3: the host-side read that used to sit here -- 393 KB over PCIe plus a sum -- left the GPU
+        # idle for a millisecond, and a 20-launch window that starts on a GPU idle for >= 1 ms takes 138 us instead of
+        # 122: tools/idle_gap.py.  It is the warm-up's job to have the GPU warm when the clock starts.)
+        run_steps(pre, pl_p)
+        run_steps(args.warmup, pl_w)
+        with torch.cuda.stream(stream):
+            env.episode_sums_device(ep_before)
         fence()
         t0 = time.perf_counter()
         ev0.record(stream)
@@ -432,6 +440,7 @@ def worker(args) -> int:
         # host gap).  This is the roofline's kernel time.
         kernel_ms = ev0.elapsed_time(ev1) / args.steps
         env.poll_error()
+        ep0 = int(ep_before[L.ACC_EPISODES].item())
         resets = int(env.episode_sums()[L.ACC_EPISODES]) - ep0
         per_rank = [elapsed]
         if use_dist:

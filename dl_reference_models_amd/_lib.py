@@ -50,7 +50,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_get_episode_stats", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
+    "mapf_step", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_get_episode_stats", "mapf_episode_stats_async", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
 )
 
 
@@ -166,6 +166,8 @@ def load():
     L.mapf_observe.argtypes = [vp, vp, vp]
     L.mapf_get_episode_stats.restype = C.c_int
     L.mapf_get_episode_stats.argtypes = [vp, vp, i32]
+    L.mapf_episode_stats_async.restype = C.c_int
+    L.mapf_episode_stats_async.argtypes = [vp, vp, vp]
     L.mapf_poll_error.restype = C.c_int
     L.mapf_poll_error.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.mapf_debug_stamps.restype = C.c_int

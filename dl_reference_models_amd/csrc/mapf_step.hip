@@ -1473,6 +1473,40 @@ int mapf_get_episode_stats(mapf_handle e, int64_t *out, int32_t reset) {
     return MAPF_OK;
 }
 
+namespace {
+// sums of the per-env episode accumulators, one workgroup: every thread adds up a strided share of the envs, the
+// workgroup's partial sums meet in LDS (64-bit adds)
+__global__ __launch_bounds__(1024) void k_episode_sums(const int *__restrict__ acc, int B, long long *__restrict__ out) {
+    __shared__ unsigned long long part[MAPF_NUM_EPISODE_ACC];
+    if (threadIdx.x < MAPF_NUM_EPISODE_ACC) part[threadIdx.x] = 0ull;
+    __syncthreads();
+    long long mine[MAPF_NUM_EPISODE_ACC];
+#pragma unroll
+    for (int k = 0; k < MAPF_NUM_EPISODE_ACC; k++) mine[k] = 0;
+    for (int env = (int)threadIdx.x; env < B; env += (int)blockDim.x) {
+        const int4 *row = reinterpret_cast<const int4 *>(acc + (size_t)env * MAPF_NUM_EPISODE_ACC);
+        const int4 a = row[0], b = row[1], c = row[2];
+        mine[0] += a.x; mine[1] += a.y; mine[2] += a.z; mine[3] += a.w;
+        mine[4] += b.x; mine[5] += b.y; mine[6] += b.z; mine[7] += b.w;
+        mine[8] += c.x; mine[9] += c.y; mine[10] += c.z; mine[11] += c.w;
+    }
+#pragma unroll
+    for (int k = 0; k < MAPF_NUM_EPISODE_ACC; k++) atomicAdd(&part[k], (unsigned long long)mine[k]);
+    __syncthreads();
+    if (threadIdx.x < MAPF_NUM_EPISODE_ACC) out[threadIdx.x] = (long long)part[threadIdx.x];
+}
+static_assert(MAPF_NUM_EPISODE_ACC == 12, "k_episode_sums reads a row as three int4");
+}  // namespace
+
+int mapf_episode_stats_async(mapf_handle e, int64_t *out, void *stream) {
+    if (!e || !out) return fail(e, MAPF_ERR_CONFIG, "null argument");
+    ON_DEVICE(e);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_episode_sums, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d_ep_acc, e->p.B, reinterpret_cast<long long *>(out));
+    HIP_TRY(e, hipGetLastError());
+    return MAPF_OK;
+}
+
 int mapf_poll_error(mapf_handle e, void *stream, int32_t *env, int32_t *agent, int32_t *value) {
     if (!e) return MAPF_ERR_CONFIG;
     int rec[4] = {0, 0, 0, 0};

@@ -348,6 +348,16 @@ class VecReferenceModel:
         self._check(self._lib.mapf_get_episode_stats(self._h, out.ctypes.data_as(C.c_void_p), 1 if reset else 0))
         return out
 
+    def episode_sums_device(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """The same sums as a device tensor (int64[12]), added up by one small launch on the current stream: no host
+        round trip, nothing synchronized, nothing cleared (mapf_episode_stats_async)."""
+        if out is None:
+            out = torch.empty(L.NUM_EPISODE_ACC, dtype=torch.int64, device=self.device)
+        if out.dtype != torch.int64 or out.device != self.device or out.numel() != L.NUM_EPISODE_ACC or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous int64[{L.NUM_EPISODE_ACC}] tensor on {self.device}")
+        self._check(self._lib.mapf_episode_stats_async(self._h, C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def episode_metrics(self, reset: bool = False, sums: np.ndarray | None = None) -> dict:
         """Mean per-episode metrics under the names the reference's RLlib callbacks log
         (src/trainers/callbacks.py: success_rate :138-181, goals_reached ... livelock_steps :325-330,

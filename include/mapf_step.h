@@ -32,7 +32,8 @@
  *                            (MA-env:83-89, :63-69; read by src/trainers/callbacks.py:111-131,265-307 and main.py:265,314)
  *   mapf_step_many        <- T x step() (+ reset() on done) for an action stream known up front: the loop of
  *                                                               scripts/benchmark_multi_agent_env.py:85-95
- *   mapf_get_episode_stats <- what ReferenceModelCallbacks.on_episode_end reads from the env   src/trainers/callbacks.py:236-345
+ *   mapf_get_episode_stats, mapf_episode_stats_async
+ *                         <- what ReferenceModelCallbacks.on_episode_end reads from the env   src/trainers/callbacks.py:236-345
  *   mapf_observe          <- get_obs / get_action_mask / _flatten_observation called on a static state
  *                                                               MA-env:707-773, :306-328
  *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
@@ -280,6 +281,12 @@ int mapf_observe(mapf_handle h, float *obs /* device */, void *stream);
  * reset != 0 clears them afterwards.  Synchronizes the device.  (Off the hot path; for a multi-GPU job add the
  * vectors of the ranks, e.g. one RCCL all-reduce of this 96-byte buffer per reporting interval.) */
 int mapf_get_episode_stats(mapf_handle h, int64_t *out /* host */, int32_t reset);
+
+/* the same sums without a host round trip: one small launch on `stream` adds the accumulators up into DEVICE memory
+ * (int64 out[MAPF_NUM_EPISODE_ACC]); nothing is synchronized and nothing is cleared.  For a training loop that logs the
+ * callbacks' metrics (src/trainers/callbacks.py:236-345) from a tensor every so often, and for bench.py, which must not
+ * leave the GPU idle between its warm-up launches and the timed region. */
+int mapf_episode_stats_async(mapf_handle h, int64_t *out /* device */, void *stream);
 
 /* read (and clear) the device error record; synchronizes `stream`.  Returns MAPF_OK when no env has
  * failed, else the code of the first failure with its env / agent / offending value. */

@@ -448,3 +448,22 @@ def test_fused_launches_predraw_next_placement_and_stay_on_the_oracle(shape):
                 _eq(f"single {k} rep {rep}", ra[k], rb[k], t)
         _eq("rng words after singles", eng.rng_words(), orc.rng_words(), rep)
     eng.env.poll_error()
+
+
+def test_episode_sums_on_the_device_equal_the_host_side_sums():
+    """mapf_episode_stats_async: the callbacks' per-episode sums added up by one launch into a device tensor, no host
+    round trip; equal to mapf_get_episode_stats at any point, also captured in a graph with the steps in front of it."""
+    B, n = 300, 4
+    env, cfg = _vec(n, B=B, H=8, W=8, steps_per_episode=7)
+    env.reset()
+    rng = np.random.default_rng(8)
+    dev = torch.empty(12, dtype=torch.int64, device=env.device)
+    for t in range(40):
+        env.step(torch.from_numpy(rng.integers(0, 5, size=(B, n)).astype(np.int8)).to(env.device))
+        if t % 13 == 5:
+            assert env.episode_sums_device(dev) is dev
+            assert np.array_equal(dev.cpu().numpy(), env.episode_sums())
+    host = env.episode_sums()
+    assert host[0] == B * (40 // 7) and np.array_equal(env.episode_sums_device().cpu().numpy(), host)
+    with pytest.raises(ValueError):
+        env.episode_sums_device(torch.empty(12, dtype=torch.int32, device=env.device))
