@@ -3288,15 +3288,7 @@ __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const L
     const int N = K::N(p);
     const uint32_t goal_real = hot.x >> 16;
     const bool pressure_real = ((hot.y >> 16) & kFlagPressure) != 0;
-    {   // while the moves are being resolved: the goal-delta quotients (MA-env:330-335) of every delta a <= 64 x 64 grid has
-        const bool norm = (K::flags(p) & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
-#pragma unroll
-        for (int k = lane; k < 128; k += 64) {
-            gd_lut[k] = goal_delta(k - 63, io.den_r, norm);
-            gd_lut[128 + k] = goal_delta(k - 63, io.den_c, norm);
-        }
-    }
-    wg_sync();  // B1: the moves (and, LDS being drained before the barrier, the table above)
+    wg_sync();  // B1: the moves (and, LDS being drained before the barrier, the caller's goal-delta table)
     // After B1 the workgroup's SIMDs are issue-bound (three busy waves each).  The observation wave goes first: its
     // stream is what the launch ends with, and the aux wave's work then fills the slots under that stream's drain.
     __builtin_amdgcn_s_setprio(3);  // (measured, us per step staggered / synchronised: obs 3, aux 1, slice 0: 5.52 / 5.08;
@@ -3322,7 +3314,7 @@ __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const L
 // image (all four planes, counters) incl. the image of a re-placed env, episode statistics, the MAY_FINISH hint.
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const Lds &l, unsigned char *aux_lds, const int lane,
-                                          const int env0, const int act, Lane &st, int *sc, const uint32_t nsg) {
+                                          const int env0, const int act, const LaneRaw &raw, int *sc, const uint32_t nsg) {
     constexpr int G = 64 / LPE;
     using gm_t = typename GMask<LPE>::type;
     const int grp = lane / LPE, a = lane % LPE;
@@ -3339,6 +3331,12 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     wg_sync();  // B1: the moves are published
     __builtin_amdgcn_s_setprio(1);  // (behind the observation wave: obs3_wave)
     MAPF_STAMP_W2(22);
+    // (Tried: unpacking behind the barrier, with the loaded registers re-defined there by an empty asm so that this wave
+    // arrives without waiting for its history planes and counters -- as written the compiler hoists the step counter's + 1
+    // above the barrier and with it a wait for every load.  Slower, 5.19 against 5.09 us: the wait then sits at the head
+    // of this wave's post-B1 chain, which is the one the launch ends with.)
+    Lane st;
+    lane_unpack(raw, true, st);
     const uint32_t cur = l.otab[lane].y >> 16;  // (the rest of the entry is the observation wave's)
     sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
     const EndDecision dec = decide_end<LPE>(io, N, lane, cur, st.goal, sc[MAPF_CTR_STEP_COUNT], nsg);
@@ -3605,6 +3603,18 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         const Lds l = carve_lds(io, lds_raw);
+        float *gd_lut = reinterpret_cast<float *>(lds_raw + io.lds_map_off + 2048);
+        {   // under the latency of the loads above: the goal-delta quotients (MA-env:330-335) of every delta a <= 64 x 64 grid
+            // has, with the correctly rounded divide (behind the loads this was 0.4 k cycles in front of B1, and the
+            // observation wave is the last to arrive there)
+            const bool norm = (K::flags(p) & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
+#pragma unroll
+            for (int k = lane; k < 128; k += 64) {
+                gd_lut[k] = goal_delta(k - 63, io.den_r, norm);
+                gd_lut[128 + k] = goal_delta(k - 63, io.den_c, norm);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wave_lds_sync();
         MAPF_STAMP_W1(10);
@@ -3616,7 +3626,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
             return;
         }
         if (io.obs || io.final_obs)
-            obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1, reinterpret_cast<float *>(lds_raw + io.lds_map_off + 2048));
+            obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1, gd_lut);
         else wg_sync();  // B1 (the other waves read the rows behind it)
         return;
     }
@@ -3703,9 +3713,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         return;
     }
     // ---- aux wave ----
-    Lane st;
-    lane_unpack(raw, true, st);
-    aux3_wave<K, LPE, MW>(p, io, l, aux_lds, lane, env0, act, st, sc, nsg);
+    aux3_wave<K, LPE, MW>(p, io, l, aux_lds, lane, env0, act, raw, sc, nsg);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
