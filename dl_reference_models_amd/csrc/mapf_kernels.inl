@@ -1225,6 +1225,26 @@ __device__ __forceinline__ void store_obs4(const ObsSink &s, unsigned off, const
     __builtin_amdgcn_raw_buffer_store_b128(w, s.rsrc, (int)off, 0, 16);  // aux 16 = sc1
 }
 
+// Write-through stores of <wave-uniform base> + <lane index> for the OTHER outputs nobody on the device reads again
+// (rewards, per-agent info, info rows; k_step3's aux wave): like the observation stream they leave L2 while the kernel
+// runs instead of at its end.  Measured per class (tools/ab_inproc.py, in phase / staggered): rewards alone -1.15 % /
+// -1.2 %; the STATE planes written through: +1.0 .. +1.5 % / +0.2 .. +0.7 % -- the next launch reads them back.
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+template <int BYTES>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, 64 * BYTES, 0x00020000);  // (64 lanes; wave-uniform operands only)
+}
+__device__ __forceinline__ void store_wt8(void *base, int lane, const uint2 v) {
+    const v2u_t w = {v.x, v.y};
+    __builtin_amdgcn_raw_buffer_store_b64(w, wt_rsrc<8>(base), lane * 8, 0, 16);  // aux 16 = sc1
+}
+__device__ __forceinline__ void store_wt4(void *base, int lane, const uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, wt_rsrc<4>(base), lane * 4, 0, 16);
+}
+__device__ __forceinline__ void store_wt2(void *base, int lane, const uint16_t v) {
+    __builtin_amdgcn_raw_buffer_store_b16(v, wt_rsrc<2>(base), lane * 2, 0, 16);
+}
+
 // full wave, one destination, compile-time shape: straight-line 16-byte copies
 template <class K, int LPE>
 __device__ __forceinline__ void flush_obs_full(const Params &p, const Io &io, float *flat, const float *stage, int lane,
@@ -2357,7 +2377,11 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
 
     // ---- everything that does not depend on the lock detector leaves now, ahead of the observation stream of the
     //      other wave: rewards, per-agent info flags, done flags and (FAST, nobody resets) the agent records ------
-    if (is_agent && !errored) {
+    if (FAST) {  // (full wave: <wave-uniform first agent> + <lane>, written through like the observation stream)
+        if (io.rewards) store_wt4(io.rewards + (size_t)env0 * N, lane, __float_as_uint(reward));
+        if (io.info_agent)
+            store_wt2(reinterpret_cast<uchar2 *>(io.info_agent) + (size_t)env0 * N, lane, (uint16_t)((blocking ? 1u : 0u) | (grs ? 0x100u : 0u)));
+    } else if (is_agent && !errored) {
         if (io.rewards) io.rewards[(size_t)env * N + a] = reward;
         if (io.info_agent) {
             uchar2 ia;
@@ -2463,7 +2487,13 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
             MAPF_STAMP(20);  // (sub-stamp: info / counters staged in LDS)
             if (io.info_all) {
                 float2 *dst = reinterpret_cast<float2 *>(io.info_all + (size_t)env0 * MAPF_INFO_ALL);
-                for (int k = lane; k < G * 7; k += 64) dst[k] = xi[k];
+#pragma unroll
+                for (int k0 = 0; k0 < G * 7; k0 += 64) {
+                    if (k0 + lane < G * 7) {
+                        const float2 v = xi[k0 + lane];
+                        store_wt8(dst + k0, lane, make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)));
+                    }
+                }
             }
             if (records_stored && lane < 3 * G) {  // the counters of an env are its first 48 of 64 bytes
                 const int g = lane / 3, j = lane - 3 * g;
@@ -3401,13 +3431,9 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     {
         const float term_reward = !done ? 0.0f : (!dec.trunc ? 1.0f : (dec.on_goal ? 0.0f : -1.0f));
         const float reward = (as.grs ? 0.5f : 0.0f) + term_reward;
-        if (io.rewards) (io.rewards + idx0)[lane] = reward;
-        if (io.info_agent) {
-            uchar2 ia;
-            ia.x = blocking ? 1 : 0;
-            ia.y = as.grs ? 1 : 0;
-            (reinterpret_cast<uchar2 *>(io.info_agent) + idx0)[lane] = ia;
-        }
+        if (io.rewards) store_wt4(io.rewards + idx0, lane, __float_as_uint(reward));
+        if (io.info_agent)  // {blocking, goal_reached_step} as two bytes
+            store_wt2(reinterpret_cast<uchar2 *>(io.info_agent) + idx0, lane, (uint16_t)((blocking ? 1u : 0u) | (as.grs ? 0x100u : 0u)));
         if (a == 0) {
             if (io.terminated) (io.terminated + env0)[grp] = (uint8_t)dec.term;
             if (io.truncated) (io.truncated + env0)[grp] = (uint8_t)dec.trunc;
@@ -3489,7 +3515,13 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
         wave_lds_sync();
         if (io.info_all) {
             float2 *dst = reinterpret_cast<float2 *>(io.info_all + (size_t)env0 * MAPF_INFO_ALL);
-            for (int k = lane; k < G * 7; k += 64) dst[k] = xi[k];
+#pragma unroll
+            for (int k0 = 0; k0 < G * 7; k0 += 64) {  // (56 float2 for groups of 8 lanes, 112 for groups of 4)
+                if (k0 + lane < G * 7) {
+                    const float2 v = xi[k0 + lane];
+                    store_wt8(dst + k0, lane, make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)));
+                }
+            }
         }
         if (lane < 3 * G) {
             const int g = lane / 3, j = lane - 3 * g;
