@@ -2,6 +2,7 @@
 """Paired A/B of the c3 step time over several builds of the library IN ONE PROCESS: one engine per build (the loader
 caches per path), the same actions, graph replays of 100 launches timed with events, the builds taking turns round after
 round -- differences of a fraction of a percent that tools/ab2.sh (one process per build) loses in its run-to-run noise.
+AB_WORKLOAD=<name> selects another workload of workloads.py (default: the headline).
 Usage on the GPU box: python3 tools/ab_inproc.py [--staggered] [--rounds 30] lib_a.so lib_b.so ..."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,13 +15,14 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 stag = "--staggered" in sys.argv
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 30
 libs = [a for a in args if a.endswith(".so")]
-b = wl.WORKLOADS[wl.HEADLINE][0]
+name = os.environ.get("AB_WORKLOAD", wl.HEADLINE)
+b = wl.WORKLOADS[name][0]
 engines = []
 for path in libs:
     os.environ["MAPF_LIB"] = os.path.abspath(path)
     import importlib
     from dl_reference_models_amd import _lib, vec_env
-    cfg = wl.workload_config(wl.HEADLINE, list(range(b)))
+    cfg = wl.workload_config(name, list(range(b)))
     env = vec_env.VecReferenceModel(cfg)
     env.reset()
     n, spe = cfg["num_agents"], int(cfg["steps_per_episode"])
