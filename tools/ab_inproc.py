@@ -2,7 +2,7 @@
 """Paired A/B of the c3 step time over several builds of the library IN ONE PROCESS: one engine per build (the loader
 caches per path), the same actions, graph replays of 100 launches timed with events, the builds taking turns round after
 round -- differences of a fraction of a percent that tools/ab2.sh (one process per build) loses in its run-to-run noise.
-AB_WORKLOAD=<name> selects another workload of workloads.py (default: the headline).
+AB_WORKLOAD=<name> selects another workload of workloads.py (default: the headline); AB_GENERIC=1 the runtime-config kernels.
 Usage on the GPU box: python3 tools/ab_inproc.py [--staggered] [--rounds 30] lib_a.so lib_b.so ..."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,8 @@ for path in libs:
     import importlib
     from dl_reference_models_amd import _lib, vec_env
     cfg = wl.workload_config(name, list(range(b)))
+    if os.environ.get("AB_GENERIC"):  # the runtime-config kernels on the same shape
+        cfg["force_generic_kernel"] = True
     env = vec_env.VecReferenceModel(cfg)
     env.reset()
     n, spe = cfg["num_agents"], int(cfg["steps_per_episode"])
