@@ -4349,8 +4349,9 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
 #endif
 
 // The headline kernel is instantiated HERE, ahead of everything the host dispatchers instantiate: it then leads the code
-// object.  (The same kernel measured 1.5-4 % slower from deeper inside the library's code object than from a small one,
-// DESIGN.md 4 "Run-time specialisation" and 5b; where it sits is the one difference.)
+// object.  (Harmless and kept; the difference it was meant to remove -- the same kernel slower when compiled at creation
+// than prebuilt -- turned out to be the compiler version of the process's hiprtc, DESIGN.md 4 "Run-time specialisation";
+// the full library and a library holding this kernel alone measure the same within the tool's 0.7 %.)
 #if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5) && !defined(MAPF_DEV_CTE)
 template __global__ void k_step3<KFixed<8, 2, kFlagsHeadline, 8, 16, 2, 1>, 8, 32, 0>(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);
 #endif

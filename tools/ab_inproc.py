@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Paired A/B of the c3 step time over several builds of the library IN ONE PROCESS: one engine per build (the loader
 caches per path), the same actions, graph replays of 100 launches timed with events, the builds taking turns round after
-round -- differences of a fraction of a percent that tools/ab2.sh (one process per build) loses in its run-to-run noise.
+round -- differences of a percent that tools/ab2.sh (one process per build) loses in its run-to-run noise.  (The same library
+listed twice differs by up to 0.7 % between its two engines -- where their buffers landed in memory -- so read
+differences below one percent as "none".)
 AB_WORKLOAD=<name> selects another workload of workloads.py (default: the headline); AB_GENERIC=1 the runtime-config kernels.
 Usage on the GPU box: python3 tools/ab_inproc.py [--staggered] [--rounds 30] lib_a.so lib_b.so ..."""
 import os, sys
