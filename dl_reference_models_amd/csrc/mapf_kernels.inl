@@ -300,6 +300,13 @@ struct KRuntime {
     __device__ static __forceinline__ int ring_stride(const Params &p) { return p.ring_stride; }
 };
 
+// The runtime-config kernels for FULL groups of 4 or 8 agents with finite episodes and sampled placements: everything
+// still comes from Params, but the background draw runs in slices inside the env workgroups and small grids get the
+// three-wave kernel, like the prebuilt shapes (round 3; mapf_create: rt_sliced).  The host guarantees N == lanes per env.
+struct KRuntimeSliced : KRuntime {
+    static constexpr bool kSlicedDraw = true;
+};
+
 template <int N_, int SR_, uint32_t FLAGS_, int DW_, int LW_, int NEARBY_, int MINN_>
 struct KFixed {
     static constexpr bool kFixed = true;

@@ -89,6 +89,7 @@ struct mapf_engine {
     int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
     int many_dense = 0;  // the fused launch has more than two waves per SIMD: the 128-register build of k_step_many
     int three_wave = 0;  // k_step3 (state / observation / aux wave): specialised finite shapes with N = 4 or 8, not dense
+    int rt_sliced = 0;   // runtime-config kernels with the sliced background draw (KRuntimeSliced): full groups of 4 / 8 agents
     // step kernels compiled for exactly this configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), else null
     hipFunction_t jit_step = nullptr, jit_many = nullptr;
     std::string jit_note = "not requested (MAPF_FLAG_JIT_SPECIALIZE)";
@@ -184,9 +185,15 @@ enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
 #define IO_HEAD_ARGS(io) (io).agents, (io).scal, (io).grid_rows, (io).actions, (io).B, (io).H, (io).W, (io).bn8, \
                          static_cast<const IoTail &>(io)
 
+template <class K, int LPE, int MW>
+hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s);
+
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP) {
+        if constexpr (LPE <= 8) {
+            if (e->rt_sliced) return launch_fixed_step<KRuntimeSliced, LPE, MW>(e, io, s);
+        }
         if constexpr (LPE < 32) {  // both register budgets, as for the specialised kernels (launch_fixed_step)
             if (e->dense)
                 LAUNCH_CHECKED((k_step<KRuntime, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
@@ -764,7 +771,12 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && atoi(f) != 0;  // test / A-B knob
         if (e->three_wave) e->dense = 0;
     };
-    plan_grid(small_full && finite_sampled && (special_id != 0 || jit_sliced));
+    // (round 3) the runtime-config kernels of such shapes take the sliced draw as well: MAPF_RT_SLICED=0 keeps them on the
+    // sampler workgroups (A/B and test knob)
+    const char *rts = getenv("MAPF_RT_SLICED");
+    const bool rt_sliced = small_full && finite_sampled && !special_id && !(rts && atoi(rts) == 0);
+    e->rt_sliced = rt_sliced && !jit_sliced;
+    plan_grid(small_full && finite_sampled && (special_id != 0 || jit_sliced || rt_sliced));
 
     Params &p = e->p;
     memset(&p, 0, sizeof(p));
@@ -851,9 +863,14 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (c.flags & MAPF_FLAG_JIT_SPECIALIZE) {
         DeviceScope scope(c.device);
         jit_specialize(e);
-        if (jit_sliced && !e->jit_step) {  // no compiled kernel after all: the runtime-config kernels draw in sampler workgroups
-            plan_grid(false);
-            e->jit_note += " [runtime-config kernels, background draw in sampler workgroups]";
+        if (jit_sliced && !e->jit_step) {  // no compiled kernel after all: the runtime-config kernels of the same launch shape
+            if (rt_sliced) {
+                e->rt_sliced = 1;  // (the grid, the LDS and the three-wave decision were planned for a sliced draw already)
+                e->jit_note += " [runtime-config kernels, sliced background draw]";
+            } else {
+                plan_grid(false);
+                e->jit_note += " [runtime-config kernels, background draw in sampler workgroups]";
+            }
         }
     }
     *out = e;

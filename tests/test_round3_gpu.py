@@ -245,16 +245,26 @@ def test_set_grids_keeps_the_visible_stream_of_envs_with_a_pending_placement():
     _eq("reset after set_grids", env.reset().cpu().numpy(), want)
 
 
-def test_failed_run_time_specialisation_falls_back_with_the_background_sampler(monkeypatch):
+@pytest.mark.parametrize("rt_sliced", [True, False])
+def test_failed_run_time_specialisation_falls_back_with_a_background_draw(monkeypatch, rt_sliced):
+    """A requested specialisation that does not come about leaves the handle on the runtime-config kernels WITH a
+    background draw: the sliced one of full 4 / 8-agent groups (three-wave kernel on a small grid), or -- the knob that
+    keeps such shapes off it -- the sampler workgroups of the two-wave kernel."""
     from dl_reference_models_amd.vec_env import VecReferenceModel
 
     monkeypatch.setenv("MAPF_JIT_FORCE_FAIL", "1")
+    if not rt_sliced:
+        monkeypatch.setenv("MAPF_RT_SLICED", "0")
     B, n = 64, 8
     cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 1, "steps_per_episode": 9, "num_envs": B,
            "grid": synth_grids(B, 10, 10, 0.1, n), "seeds": list(range(B)), "jit_specialize": True}
     env = VecReferenceModel(cfg)
     info = env.launch_info()
-    assert not info["jit"] and "sampler workgroups" in info["jit_note"] and info["threads"] == 128
+    assert not info["jit"]
+    if rt_sliced:
+        assert "sliced background draw" in info["jit_note"] and info["threads"] == 192
+    else:
+        assert "sampler workgroups" in info["jit_note"] and info["threads"] == 128
     orc = OracleStepper(cfg["grid"], cfg, seeds=cfg["seeds"])
     _eq("reset", env.reset().cpu().numpy(), orc.reset())
     rng = np.random.default_rng(2)
@@ -467,3 +477,51 @@ def test_episode_sums_on_the_device_equal_the_host_side_sums():
     assert host[0] == B * (40 // 7) and np.array_equal(env.episode_sums_device().cpu().numpy(), host)
     with pytest.raises(ValueError):
         env.episode_sums_device(torch.empty(12, dtype=torch.int32, device=env.device))
+
+
+@pytest.mark.parametrize("shape", [
+    (130, 12, 14, 8, 1, 7, {}),                                         # three-wave runtime kernel, 3 x 3 windows
+    (67, 16, 16, 4, 3, 5, {"include_action_mask_in_obs": False}),       # groups of 4, 7 x 7 windows (64-bit masks)
+    (40, 20, 20, 8, 4, 9, {"livelock_window_steps": 30, "deadlock_window_steps": 20}),  # 9 x 9 windows, int16 distance ring
+    (64, 9, 9, 8, 2, 1, {"lock_nearby_manhattan": 3, "lock_min_neighbors": 2}),           # episodes of one step
+    (200, 10, 10, 4, 2, 3, {"enable_lock_metrics": False}),
+])
+@pytest.mark.parametrize("dense", [None, "1"])
+def test_runtime_config_kernels_with_the_sliced_draw_match_the_oracle(shape, dense, monkeypatch):
+    """Full groups of 4 or 8 agents on the RUNTIME-CONFIG kernels (no prebuilt shape matches, no specialisation
+    requested) draw their next placement in slices like the prebuilt shapes and, on small grids, run the three-wave kernel
+    (KRuntimeSliced); dense = the two-wave 128-register build with the slices.  Staggered phases, single steps and fused
+    launches mixed, generator words included."""
+    import torch
+
+    B, H, W, N, sr, spe, extra = shape
+    if dense:
+        monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
+    cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": sr, "include_action_mask_in_obs": True, "steps_per_episode": spe}
+    cfg.update(extra)
+    grids = synth_grids(B, H, W, 0.1, N, base_seed=44_000)
+    seeds = list(range(300, 300 + B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    info = eng.env.launch_info()
+    assert info["specialized_kernel"] == 0 and info["threads"] == (128 if dense else 192)
+    _eq("reset", eng.reset(), orc.reset())
+    counts = np.arange(B) % spe
+    eng.set_step_counts(counts)
+    orc.set_step_counts(counts)
+    rng = np.random.default_rng(6)
+    for t in range(90):
+        a = rng.integers(0, 5, size=(B, N)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            _eq(k, ra[k], rb[k], t)
+        if t % 11 == 0:
+            _eq("rng words", eng.rng_words(), orc.rng_words(), t)
+            _eq("goals", eng.goals(), orc.goals(), t)
+    acts = rng.integers(0, 5, size=(25, B, N)).astype(np.int8)
+    out = eng.env.step_many(torch.from_numpy(acts).to(eng.env.device), obs_mode=2)
+    for t in range(25):
+        r = orc.step(acts[t])
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all"):
+            _eq(f"fused {k}", out[k][t].cpu().numpy(), r[k], t)
+    _eq("rng words at the end", eng.rng_words(), orc.rng_words())
+    eng.env.poll_error()

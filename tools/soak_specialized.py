@@ -7,7 +7,7 @@ also end by success at arbitrary steps), with and without the terminal observati
 positions, goals and generator words every few steps.  tests/test_soak_gpu.py runs a short one (run_soak below); the
 long ones are recorded in DESIGN.md section 2.
 Usage: python tools/soak_specialized.py [master_seed] [cases]
-Environment: SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
+Environment: SOAK_GENERIC=1 (the runtime-config kernels on the same shapes), SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
 reset, the A/B), SOAK_ONLY=<case> (run one case of the sequence), SOAK_WATCH=<case>:<env> (print that env's placement slot
 and staging buffer before every step).  Cases are NOT independent on the GPU side: what a kernel finds in LDS depends on
 the launches before it, so a failure is reported with its case number in the sequence."""
@@ -51,8 +51,10 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
             orc.reset()
         else:
             kw = {"force_sequential_reset": True} if sequential else {}
+            if os.environ.get("SOAK_GENERIC"):  # the same shapes on the runtime-config kernels (full groups of 4 / 8 agents:
+                kw["force_generic_kernel"] = True  # sliced draw + three-wave kernel since round 3; MAPF_RT_SLICED=0: sampler workgroups)
             eng = EngineStepper(grids, cfg, seeds=seeds, want_final_obs=want_final, **kw)
-            assert eng.env.launch_info()["specialized_kernel"] in (1, 2, 4, 5, 6), eng.env.launch_info()
+            assert eng.env.launch_info()["specialized_kernel"] in ((0,) if os.environ.get("SOAK_GENERIC") else (1, 2, 4, 5, 6)), eng.env.launch_info()
             _eq("reset obs", eng.reset(), orc.reset())
         counts = rng.integers(0, cfg["steps_per_episode"], size=B)
         eng.set_step_counts(counts); orc.set_step_counts(counts)
