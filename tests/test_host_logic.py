@@ -187,3 +187,16 @@ def test_bench_refuses_more_gpus_than_the_node_has_instead_of_hanging():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "1"],
                        capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k != "RANK"})
     assert r.returncode == 1 and "exposes" in r.stderr and r.stdout.strip() == ""
+
+
+def test_measurement_and_development_tools_compile():
+    """tools/*.py and bench.py are what the numbers in DESIGN.md were made with: they must at least parse (they run on a
+    GPU box only; a syntax error there costs a GPU call)."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
