@@ -1570,6 +1570,113 @@ __device__ __forceinline__ void draw_shuffle16(const Params &p, int env, int16_t
     }
 }
 
+// Floyd's sampling and the tail shuffle for lists of more than LPE (up to 2 LPE) values WITHOUT a loop over the elements:
+// element k and k + LPE live in lane k of the group; all masks are the group's (gballot).  NumPy writes both as 2N
+// dependent iterations (40 k cycles of one wave at N = 64, during which the other 1 023 wait for the launch to end).
+//
+// ---- Floyd.  chosen_k = j_k = base + k if val_k is in the set when its turn comes, else val_k.  A value v is in the
+//      set at time k iff it was DRAWN before (val_s == v, s < k: whoever drew it first put it there, unless it already
+//      was) or it is the j of an earlier element that collided (v = j_u, u < k, element u took j_u); nothing else ever
+//      enters the set.  So
+//          coll_k = dup_k | (u_k < k & coll[u_k]),   u_k = val_k - base,
+//      with dup_k from equality masks built by ballots over the 12 value bits (cells of a 64 x 64 grid), and the second
+//      term a chain through LOWER indices that only exists for values in the j range (2N / F of them): iterated to its
+//      fixed point, one or two rounds of two ballots in practice.
+template <int LPE>
+__device__ __forceinline__ void draw_floyd_par(const uint16_t *vals, int lane, int a, int size, int pop, int &c0, int &c1) {
+    const uint64_t gm = group_mask<LPE>();
+    const int base = pop - size;
+    const bool e1 = a + LPE < size;
+    const int v0 = (int)vals[min(a, size - 1)], v1 = (int)vals[min(a + LPE, size - 1)];
+    const uint64_t below = (1ull << a) - 1ull;
+    uint64_t q00 = gm, q10 = gm, q11 = gballot<LPE>(e1, lane);  // elements of set s equal to my v_x: q<x><s>
+#pragma unroll 1  // (rare path inside the step kernels: unrolled, the two loops are 12 KB of a 70 KB kernel and every step
+                  // of c5 pays 2 % for them in instruction-cache misses)
+    for (int b = 0; b < 12; b++) {
+        const bool x0 = (v0 >> b) & 1, x1 = (v1 >> b) & 1;
+        const uint64_t B0 = gballot<LPE>(x0, lane), B1 = gballot<LPE>(x1, lane);
+        q00 &= x0 ? B0 : ~B0;
+        q10 &= x1 ? B0 : ~B0;
+        q11 &= x1 ? B1 : ~B1;
+    }
+    const bool dup0 = (q00 & below) != 0, dup1 = e1 && (q10 != 0 || (q11 & below) != 0);
+    const int u0 = v0 - base, u1 = v1 - base;
+    const bool r0 = u0 >= 0 && u0 < a, r1 = e1 && u1 >= 0 && u1 < a + LPE;
+    bool k0 = dup0, k1 = dup1;
+    for (int it = 0; it < size; it++) {  // (the chain is shorter than the list: the bound is structural)
+        const uint64_t C0 = gballot<LPE>(k0, lane), C1 = gballot<LPE>(k1, lane);
+        const bool n0 = dup0 || (r0 && ((C0 >> (u0 & (LPE - 1))) & 1ull));
+        const bool n1 = dup1 || (r1 && (((u1 < LPE ? C0 : C1) >> (u1 & (LPE - 1))) & 1ull));
+        const bool changed = n0 != k0 || n1 != k1;
+        k0 = n0;
+        k1 = n1;
+        if (!__any(changed)) break;
+    }
+    c0 = k0 ? base + a : v0;
+    c1 = k1 ? base + a + LPE : v1;
+}
+// ---- tail shuffle: for i = size-1 .. 1: swap(idx[i], idx[J_i]), J_i <= i.  Position i is final after step i and receives
+//      what position J_i holds then.  A position q <= i holds, before step i, what the NEXT step after i aiming at q put
+//      there (the steps run downwards: that is the latest write), else its original element; and what step x puts
+//      somewhere is what position x held before step x, i.e. what the first step above x aiming at x put there -- up(x) --
+//      and so on: a forest of pointers to higher indices.  final[i] = orig[root(nx(i))], nx(i) = the next step above i
+//      with the same aim (or orig[J_i] if there is none).  nx and up are lowest-set-bit queries on equality masks over
+//      the bits of J; the roots come from pointer doubling on a 2 LPE-byte table (<= log2(2 LPE) rounds, 2-4 in practice).
+//      c0 / c1: the chosen values number a and a + LPE; raw: the group's scratch (its raw outputs were consumed by
+//      stage a); out[2N] receives idx.  (A group that is not drawing runs along on junk: its stores are guarded by ok.)
+template <int LPE>
+__device__ __forceinline__ void draw_shuffle_par(const Params &p, int env, uint32_t *raw, const uint16_t *vals, int16_t *out,
+                                                 int lane, int a, int size, int c0, int c1, bool ok) {
+    (void)p; (void)env;
+    constexpr int kBits = LPE == 64 ? 7 : (LPE == 32 ? 6 : (LPE == 16 ? 5 : (LPE == 8 ? 4 : 3)));
+    const uint64_t gm = group_mask<LPE>();
+    const bool e1 = a + LPE < size;
+    const uint64_t above = (a == LPE - 1) ? 0ull : ((~0ull << (a + 1)) & gm);
+    const bool s0 = a >= 1, s1 = e1;  // element i is a step (i = 0 is not: J_0 := 0)
+    const int J0 = s0 ? (int)vals[size + size - 1 - a] & (2 * LPE - 1) : 0;
+    const int J1 = s1 ? (int)vals[size + size - 1 - min(a + LPE, size - 1)] & (2 * LPE - 1) : 0;
+    const uint64_t V0 = gm & ~1ull, V1 = gballot<LPE>(s1, lane);
+    uint64_t n00 = V0, n01 = V1, n11 = V1;  // steps of set s aiming where element x aims: n<x><s>
+    uint64_t w00 = V0, w01 = V1, w11 = V1;  // steps of set s aiming AT element x (index a / a + LPE): w<x><s>
+#pragma unroll 1
+    for (int b = 0; b < kBits; b++) {
+        const bool y0 = (J0 >> b) & 1, y1 = (J1 >> b) & 1;
+        const uint64_t B0 = gballot<LPE>(y0, lane), B1 = gballot<LPE>(y1, lane);
+        const bool i0 = (a >> b) & 1, i1 = ((a + LPE) >> b) & 1;  // bits of my indices a and a + LPE
+        n00 &= y0 ? B0 : ~B0;
+        n01 &= y0 ? B1 : ~B1;
+        n11 &= y1 ? B1 : ~B1;
+        w00 &= i0 ? B0 : ~B0;
+        w01 &= i0 ? B1 : ~B1;
+        w11 &= i1 ? B1 : ~B1;
+    }
+    auto lowest = [&](uint64_t m0, uint64_t m1, int none) -> int {  // lowest step in (set 0 | set 1), else `none`
+        return m0 ? (int)__builtin_ctzll(m0) : (m1 ? LPE + (int)__builtin_ctzll(m1) : none);
+    };
+    const int nx0 = lowest(n00 & above, n01, -1), nx1 = lowest(0ull, n11 & above, -1);
+    int p0 = lowest(w00 & above, w01, a), p1 = lowest(0ull, w11 & above, a + LPE);  // up(x), or x itself: a root
+    uint8_t *ptr = reinterpret_cast<uint8_t *>(raw);
+    int16_t *chosen = reinterpret_cast<int16_t *>(raw) + LPE;  // [2 LPE] behind the 2 LPE pointer bytes
+    chosen[a] = (int16_t)c0;
+    chosen[a + LPE] = (int16_t)c1;
+    for (int it = 0; it <= kBits; it++) {
+        ptr[a] = (uint8_t)p0;
+        ptr[a + LPE] = (uint8_t)p1;
+        wave_lds_sync();
+        const int t0 = ptr[p0], t1 = ptr[p1];
+        const bool changed = t0 != p0 || t1 != p1;
+        p0 = t0;
+        p1 = t1;
+        wave_lds_sync();
+        if (!__any(changed)) break;
+    }
+    const int g0 = nx0 >= 0 ? (int)ptr[nx0] : J0, g1 = nx1 >= 0 ? (int)ptr[nx1] : J1;
+    MAPF_CHK(p, !ok || (unsigned)g0 < (unsigned)size, 4, env, g0);
+    MAPF_CHK(p, !(ok && e1) || (unsigned)g1 < (unsigned)size, 4, env, g1);
+    if (ok) out[a] = chosen[g0];
+    if (ok && e1) out[a + LPE] = chosen[g1];
+}
+
 // Second half: Floyd's sampling and the tail shuffle on vals[] (group scratch) -> out[2N] (group scratch).
 template <int LPE>
 __device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *scr, int lane, int a, bool ok, int N, int pop) {
@@ -1587,99 +1694,11 @@ __device__ __forceinline__ void draw_stage_b(const Params &p, int env, int16_t *
         // Longer lists (N > 8: up to 128 values at N = 64).  Floyd's sampling and the tail shuffle are sequential as
         // NumPy writes them, 2N dependent iterations each (40 k cycles of one wave at N = 64, during which the other
         // 1 023 wait for the launch to end).  With one group per wave (N > 32) both are restated with short chains:
-        if (LPE == 64 && size > 64) {
-            // One group per wave, 66 .. 128 values, element k and k + 64 in lane k (fewer values in a 64-lane group --
-            // lanes_per_env forced wider than the agents need -- take the loop below).  No loop over the elements:
-            //
-            // ---- Floyd.  chosen_k = j_k = base + k if val_k is in the set when its turn comes, else val_k.  A value v
-            //      is in the set at time k iff it was DRAWN before (val_s == v, s < k: whoever drew it first put it
-            //      there, unless it already was) or it is the j of an earlier element that collided (v = j_u, u < k,
-            //      element u took j_u); nothing else ever enters the set.  So
-            //          coll_k = dup_k | (u_k < k & coll[u_k]),   u_k = val_k - base,
-            //      with dup_k from equality masks built by ballots over the 12 value bits (cells of a 64 x 64 grid), and
-            //      the second term a chain through LOWER indices that only exists for values in the j range (2N / F of
-            //      them): iterated to its fixed point, one or two rounds of two ballots in practice.
-            const int base = pop - size;
-            const bool e1 = a + 64 < size;
-            const int v0 = (int)vals[min(a, size - 1)], v1 = (int)vals[min(a + 64, size - 1)];
-            const uint64_t below = (1ull << a) - 1ull, above = a == 63 ? 0ull : (~0ull << (a + 1));
-            uint64_t q00 = ~0ull, q10 = ~0ull, q11 = __ballot(e1);  // elements of set s equal to my v_x: q<x><s>
-#pragma unroll 1  // (rare path inside the step kernels: unrolled, the two loops are 12 KB of a 70 KB kernel and every step
-                  // of c5 pays 2 % for them in instruction-cache misses)
-            for (int b = 0; b < 12; b++) {
-                const bool x0 = (v0 >> b) & 1, x1 = (v1 >> b) & 1;
-                const uint64_t B0 = __ballot(x0), B1 = __ballot(x1);
-                q00 &= x0 ? B0 : ~B0;
-                q10 &= x1 ? B0 : ~B0;
-                q11 &= x1 ? B1 : ~B1;
-            }
-            const bool dup0 = (q00 & below) != 0, dup1 = e1 && (q10 != 0 || (q11 & below) != 0);
-            const int u0 = v0 - base, u1 = v1 - base;
-            const bool r0 = u0 >= 0 && u0 < a, r1 = e1 && u1 >= 0 && u1 < a + 64;
-            bool k0 = dup0, k1 = dup1;
-            for (int it = 0; it < size; it++) {  // (the chain is shorter than the list: the bound is structural)
-                const uint64_t C0 = __ballot(k0), C1 = __ballot(k1);
-                const bool n0 = dup0 || (r0 && ((C0 >> (u0 & 63)) & 1ull));
-                const bool n1 = dup1 || (r1 && (((u1 < 64 ? C0 : C1) >> (u1 & 63)) & 1ull));
-                const bool changed = n0 != k0 || n1 != k1;
-                k0 = n0;
-                k1 = n1;
-                if (!__any(changed)) break;
-            }
-            c0 = k0 ? base + a : v0;
-            c1 = k1 ? base + a + 64 : v1;
-            // ---- tail shuffle: for i = size-1 .. 1: swap(idx[i], idx[J_i]), J_i <= i.  Position i is final after step i
-            //      and receives what position J_i holds then.  A position q <= i holds, before step i, what the NEXT
-            //      step after i aiming at q put there (the steps run downwards: that is the latest write), else its
-            //      original element; and what step x puts somewhere is what position x held before step x, i.e. what the
-            //      first step above x aiming at x put there -- up(x) -- and so on: a forest of pointers to higher
-            //      indices.  final[i] = orig[root(nx(i))], nx(i) = the next step above i with the same aim (or
-            //      orig[J_i] if there is none).  nx and up are lowest-set-bit queries on equality masks over the 7 bits
-            //      of J; the roots come from pointer doubling on a 128-byte table (<= 7 rounds, 2-4 in practice).
-            const bool s0 = a >= 1, s1 = e1;  // element i is a step (i = 0 is not: J_0 := 0)
-            const int J0 = s0 ? (int)vals[size + size - 1 - a] & 127 : 0;
-            const int J1 = s1 ? (int)vals[size + size - 1 - min(a + 64, size - 1)] & 127 : 0;
-            const uint64_t V0 = ~1ull, V1 = __ballot(s1);
-            uint64_t n00 = V0, n01 = V1, n11 = V1;  // steps of set s aiming where element x aims: n<x><s>
-            uint64_t w00 = V0, w01 = V1, w11 = V1;  // steps of set s aiming AT element x (index a / a + 64): w<x><s>
-#pragma unroll 1  // (rare path inside the step kernels: unrolled, the two loops are 12 KB of a 70 KB kernel and every step
-                  // of c5 pays 2 % for them in instruction-cache misses)
-            for (int b = 0; b < 7; b++) {
-                const bool y0 = (J0 >> b) & 1, y1 = (J1 >> b) & 1;
-                const uint64_t B0 = __ballot(y0), B1 = __ballot(y1);
-                const bool i0 = (a >> b) & 1, i1 = b == 6 ? true : i0;  // bits of my indices a and a + 64
-                n00 &= y0 ? B0 : ~B0;
-                n01 &= y0 ? B1 : ~B1;
-                n11 &= y1 ? B1 : ~B1;
-                w00 &= i0 ? B0 : ~B0;
-                w01 &= i0 ? B1 : ~B1;
-                w11 &= i1 ? B1 : ~B1;
-            }
-            auto lowest = [&](uint64_t m0, uint64_t m1, int none) -> int {  // lowest step in (set 0 | set 1), else `none`
-                return m0 ? (int)__builtin_ctzll(m0) : (m1 ? 64 + (int)__builtin_ctzll(m1) : none);
-            };
-            const int nx0 = lowest(n00 & above, n01, -1), nx1 = lowest(0ull, n11 & above, -1);
-            int p0 = lowest(w00 & above, w01, a), p1 = lowest(0ull, w11 & above, a + 64);  // up(x), or x itself: a root
-            uint8_t *ptr = reinterpret_cast<uint8_t *>(raw);       // (the raw outputs were consumed by stage a)
-            int16_t *chosen = reinterpret_cast<int16_t *>(raw) + 64;  // [128] behind the 128 pointer bytes
-            chosen[a] = (int16_t)c0;
-            chosen[a + 64] = (int16_t)c1;
-            for (int it = 0; it < 8; it++) {
-                ptr[a] = (uint8_t)p0;
-                ptr[a + 64] = (uint8_t)p1;
-                wave_lds_sync();
-                const int t0 = ptr[p0], t1 = ptr[p1];
-                const bool changed = t0 != p0 || t1 != p1;
-                p0 = t0;
-                p1 = t1;
-                wave_lds_sync();
-                if (!__any(changed)) break;
-            }
-            const int g0 = nx0 >= 0 ? (int)ptr[nx0] : J0, g1 = nx1 >= 0 ? (int)ptr[nx1] : J1;
-            MAPF_CHK(p, !ok || (unsigned)g0 < (unsigned)size, 4, env, g0);
-            MAPF_CHK(p, !(ok && e1) || (unsigned)g1 < (unsigned)size, 4, env, g1);
-            if (ok) out[a] = chosen[g0];
-            if (ok && e1) out[a + 64] = chosen[g1];
+        if (size > LPE) {  // two elements per lane: element k and k + LPE in lane k of the group (N = 9 .. 16 in groups of
+                           // 16 lanes, 17 .. 32 in groups of 32, 33 .. 64 in one wave); fewer values in a wide group --
+                           // lanes_per_env forced wider than the agents need -- take the loop below
+            draw_floyd_par<LPE>(vals, lane, a, size, pop, c0, c1);
+            draw_shuffle_par<LPE>(p, env, raw, vals, out, lane, a, size, c0, c1, ok);
         } else {
             for (int k = 0; k < size; k++) {
                 const int val = (int)vals[k], j = pop - size + k;
