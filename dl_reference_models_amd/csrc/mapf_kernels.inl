@@ -173,7 +173,7 @@ struct IoTail {
     uint32_t *stage_vals;
     const uint16_t *free_cells;
     uint64_t *vis_rng;
-    const uint64_t *jump_c;      // [B][16][2] per env: S_q * inc mod 2^128 (hi, lo), q = 1 .. 16 -- the increment of a
+    const uint64_t *jump_c;      // [B][32][2] per env: S_q * inc mod 2^128 (hi, lo), q = 1 .. 32 -- the increment of a
                                  // PCG64 stream never changes, so this half of the jump-ahead (state_q = A_q * state +
                                  // S_q * inc) is a table written when the stream is set (mapf_set_rng_state / set_state)
 };
@@ -303,6 +303,7 @@ struct KRuntime {
 // The runtime-config kernels for FULL groups of 4 or 8 agents with finite episodes and sampled placements: everything
 // still comes from Params, but the background draw runs in slices inside the env workgroups and small grids get the
 // three-wave kernel, like the prebuilt shapes (round 3; mapf_create: rt_sliced).  The host guarantees N == lanes per env.
+// (also full groups of 16: their draw is sliced, the kernel stays the two-wave one)
 struct KRuntimeSliced : KRuntime {
     static constexpr bool kSlicedDraw = true;
 };
@@ -310,10 +311,10 @@ struct KRuntimeSliced : KRuntime {
 template <int N_, int SR_, uint32_t FLAGS_, int DW_, int LW_, int NEARBY_, int MINN_>
 struct KFixed {
     static constexpr bool kFixed = true;
-    // finite episodes with sampled placements and at most 16 cells to draw: the background draw runs in slices in
-    // the observation wave of the env's own workgroup (draw_slice), no sampler workgroups
-    // (the slices assume a full group, N = lanes per env: 4 or 8; other small N take the sampler workgroups)
-    static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && (N_ == 4 || N_ == 8);
+    // finite episodes with sampled placements and full groups of 4, 8 or 16 agents: the background draw runs in slices
+    // inside the env's own workgroup (draw_slice), no sampler workgroups
+    // (the slices assume N = lanes per env, two values per lane; other N take the sampler workgroups)
+    static constexpr bool kSlicedDraw = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && (N_ == 4 || N_ == 8 || N_ == 16);
     static constexpr bool kSamplerFront = (FLAGS_ & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC)) == 0 && !kSlicedDraw;
     // wide groups (N > 16): the specialisation is only used with the LDS cell map (mapf_create falls back to the
     // runtime-config kernel otherwise), so the all-pairs walk is not compiled in: at N = 64 its unrolled loops were
@@ -2695,7 +2696,7 @@ struct DrawReq {
 __device__ __forceinline__ void draw_request_jump(const Io &io, int a, int env, int LPE, int which, DrawReq &d) {
     const int q = a + 1 + (which == 0 ? LPE : 0);  // index 0: slice 1 (the later half), 1: slice 2
     d.ja[which] = *reinterpret_cast<const uint4 *>(&kPcgJumpA[min(q, 64)][0]);
-    d.cq[which] = reinterpret_cast<const uint4 *>(io.jump_c)[(size_t)env * 16 + min(q, 16) - 1];
+    d.cq[which] = reinterpret_cast<const uint4 *>(io.jump_c)[(size_t)env * 32 + min(q, 32) - 1];
 }
 // With the wave's first loads: the env's slot word and hint, and -- speculatively, 116 bytes per env and launch, so that
 // a slice starts computing at B0 instead of a memory round trip later (it has to be done by B1) -- the free-cell count,
@@ -2836,16 +2837,18 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         }
         wave_lds_sync();
         int c0 = (int)vals[a], c1 = -1;  // (second half: the first half left this lane's chosen value in its place)
-        draw_floyd16<LPE>(hs, lane, a, N, d.pop, c0, c1, half);
+        const bool whole = 2 * N > 16;   // 32 values (N = 16): the loop-free formulation does both halves in this slice
+        if (whole) draw_floyd_par<LPE>(vals, lane, a, 2 * N, d.pop, c0, c1);
+        else draw_floyd16<LPE>(hs, lane, a, N, d.pop, c0, c1, half);
         wave_lds_sync();
         if (on) {
-            if (half == 0) vals[a] = (uint16_t)c0;
-            else vals[a + LPE] = (uint16_t)c1;
+            if (half == 0 || whole) vals[a] = (uint16_t)c0;
+            if (half == 1 || whole) vals[a + LPE] = (uint16_t)c1;
         }
         wave_lds_sync();
         if (on) {
             sv[a] = vals32[a];  // dwords 0 .. LPE-1 hold the 2N chosen values; the shuffle indices behind them stay
-            if (a == 0) slot[0] = half == 0 ? kSlotStaged4 : kSlotStaged5;
+            if (a == 0) slot[0] = (half == 0 && !whole) ? kSlotStaged4 : kSlotStaged5;
         }
     }
     if (__any(stage == 6)) {  // ---- tail shuffle -> idx[2N]
@@ -2856,7 +2859,8 @@ __device__ __forceinline__ void draw_slice(const Params &p, const Io &io, int16_
         }
         wave_lds_sync();
         const int c0 = (int)vals[a], c1 = (int)vals[a + LPE];
-        draw_shuffle16<LPE>(p, env, hs, lane, a, N, c0, c1, on);
+        if (2 * N > 16) draw_shuffle_par<LPE>(p, env, raw, vals, hs + sample_out_off_i16(N), lane, a, 2 * N, c0, c1, on);
+        else draw_shuffle16<LPE>(p, env, hs, lane, a, N, c0, c1, on);
         wave_lds_sync();
         if (on) {
             sv[a] = out32[a];  // N dwords = idx[2N]

@@ -116,7 +116,7 @@ struct mapf_engine {
     int *d_err = nullptr;
     int *d_ep_acc = nullptr;
     uint32_t *d_stage_vals = nullptr;  // [B][2N] bounded draws of a staged background draw (Params::stage_vals)
-    uint64_t *d_jump_c = nullptr;   // [B][16][2] S_q * inc of every env's stream (Io::jump_c), rewritten whenever the streams are set
+    uint64_t *d_jump_c = nullptr;   // [B][32][2] S_q * inc of every env's stream (Io::jump_c), rewritten whenever the streams are set
     uint64_t *d_vis_rng = nullptr;  // [B][6] visible stream state of envs whose placement slot is pending (Params::vis_rng)
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
@@ -191,7 +191,7 @@ hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s);
 template <int LPE, int MW>
 hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP) {
-        if constexpr (LPE <= 8) {
+        if constexpr (LPE <= 16) {
             if (e->rt_sliced) return launch_fixed_step<KRuntimeSliced, LPE, MW>(e, io, s);
         }
         if constexpr (LPE < 32) {  // both register budgets, as for the specialised kernels (launch_fixed_step)
@@ -229,7 +229,7 @@ constexpr int mask_width_for(int sr) {
 // small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
 template <class K, int LPE, int MW>
 hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
-    if constexpr (K::kSlicedDraw) {
+    if constexpr (K::kSlicedDraw && LPE <= 8) {
         if (e->three_wave)
             LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(192), e->lds_bytes, s, e->d_params,
                            IO_HEAD_ARGS(io));
@@ -588,19 +588,19 @@ static hipError_t force_may_finish(mapf_engine *e) {
     return hipMemset2D(e->d_scal + MAPF_CTR_MAY_FINISH, kScalInts * sizeof(int), 1, sizeof(int), (size_t)e->p.B);
 }
 
-// Io::jump_c: for every env the second half of the PCG64 jump-ahead, S_q * inc mod 2^128 for q = 1 .. 16, with
+// Io::jump_c: for every env the second half of the PCG64 jump-ahead, S_q * inc mod 2^128 for q = 1 .. 32, with
 // S_1 = 1, S_(q+1) = S_q * M + 1 (state_q = M^q * state + S_q * inc).  words = [B][6] stream words (inc in words 2, 3).
 static int upload_jump_table(mapf_engine *e, const uint64_t *words) {
     const int B = e->p.B;
-    std::vector<uint64_t> tab((size_t)B * 32);
+    std::vector<uint64_t> tab((size_t)B * 64);
     const unsigned __int128 M = ((unsigned __int128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
     for (int b = 0; b < B; b++) {
         const unsigned __int128 inc = ((unsigned __int128)words[(size_t)b * 6 + 2] << 64) | words[(size_t)b * 6 + 3];
         unsigned __int128 S = 1;
-        for (int q = 1; q <= 16; q++) {
+        for (int q = 1; q <= 32; q++) {
             const unsigned __int128 c = S * inc;
-            tab[(size_t)b * 32 + 2 * (q - 1)] = (uint64_t)(c >> 64);
-            tab[(size_t)b * 32 + 2 * (q - 1) + 1] = (uint64_t)c;
+            tab[(size_t)b * 64 + 2 * (q - 1)] = (uint64_t)(c >> 64);
+            tab[(size_t)b * 64 + 2 * (q - 1) + 1] = (uint64_t)c;
             S = S * M + 1;
         }
     }
@@ -749,7 +749,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     // plan_grid(sliced) is called again when a requested run-time specialisation does not come about.
     const bool finite_sampled = !cte && !(c.flags & (MAPF_FLAG_LIFELONG | MAPF_FLAG_DETERMINISTIC));
     const int special_id = cte ? 0 : match_specialization(c, lpe, c.lock_nearby_manhattan);
-    const bool small_full = (c.num_agents == 4 || c.num_agents == 8) && lpe == c.num_agents;
+    const bool small_full = (c.num_agents == 4 || c.num_agents == 8 || c.num_agents == 16) && lpe == c.num_agents;
     const bool jit_sliced = !special_id && !cte && (c.flags & MAPF_FLAG_JIT_SPECIALIZE) && !(c.flags & MAPF_FLAG_GENERIC_KERNEL) &&
                             lpe == pick_lpe(N) && small_full && finite_sampled;
     int cus = 0;
@@ -767,8 +767,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // SIMD with three waves per workgroup (beyond that the two-wave kernel's 128-register build is the one that fits)
         e->many_dense = (int64_t)e->blocks * (many_threads(lpe) / 64) > (int64_t)2 * 4 * cus;
         if (const char *f = getenv("MAPF_FORCE_DENSE")) e->many_dense = atoi(f) != 0;
-        e->three_wave = sliced && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
-        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && atoi(f) != 0;  // test / A-B knob
+        e->three_wave = sliced && lpe <= 8 && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
+        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && lpe <= 8 && atoi(f) != 0;  // test / A-B knob
         if (e->three_wave) e->dense = 0;
     };
     // (round 3) the runtime-config kernels of such shapes take the sliced draw as well: MAPF_RT_SLICED=0 keeps them on the
@@ -899,8 +899,8 @@ static int alloc_device_state(mapf_engine *e) {
     e->d_rng = streams_of(e->d_scal, B, N);
     e->d_n_free = free_counts_of(e->d_scal, B, N);
     HIP_TRY(e, hipMalloc(&e->d_vis_rng, (size_t)B * 6 * sizeof(uint64_t)));
-    HIP_TRY(e, hipMalloc(&e->d_jump_c, (size_t)B * 32 * sizeof(uint64_t)));
-    HIP_TRY(e, hipMemset(e->d_jump_c, 0, (size_t)B * 32 * sizeof(uint64_t)));
+    HIP_TRY(e, hipMalloc(&e->d_jump_c, (size_t)B * 64 * sizeof(uint64_t)));
+    HIP_TRY(e, hipMemset(e->d_jump_c, 0, (size_t)B * 64 * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_stage_vals, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
     HIP_TRY(e, hipMemset(e->d_stage_vals, 0, (size_t)B * stage_dwords(N) * sizeof(uint32_t)));
     p.stage_vals = e->d_stage_vals;

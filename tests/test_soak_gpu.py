@@ -58,8 +58,9 @@ def test_checking_build_latches_an_index_outside_its_region(monkeypatch):
             env.poll_error()
 
 
-@pytest.mark.parametrize("master,cases,dense,sampler", [(2030, 30, None, False), (2031, 15, "1", False), (2032, 15, None, True)])
-def test_short_soak_of_the_runtime_config_kernels(master, cases, dense, sampler, monkeypatch):
+@pytest.mark.parametrize("master,cases,dense,sampler,only_n", [(2030, 30, None, False, None), (2031, 15, "1", False, None),
+                                                              (2032, 15, None, True, None), (2033, 15, None, False, 16)])
+def test_short_soak_of_the_runtime_config_kernels(master, cases, dense, sampler, only_n, monkeypatch):
     """The same soak with the runtime-config kernels forced onto the prebuilt shapes (SOAK_GENERIC): full groups of 4 / 8
     agents draw in slices and run the three-wave kernel (KRuntimeSliced), its two-wave 128-register build (dense), or --
     MAPF_RT_SLICED=0 -- the sampler workgroups they used before round 3."""
@@ -70,5 +71,5 @@ def test_short_soak_of_the_runtime_config_kernels(master, cases, dense, sampler,
     if sampler:
         monkeypatch.setenv("MAPF_RT_SLICED", "0")
     lines = []
-    err = run_soak(master, cases, log=lines.append)
+    err = run_soak(master, cases, only_n=only_n, log=lines.append)
     assert err is None, err + "\n" + "\n".join(lines[-8:])
