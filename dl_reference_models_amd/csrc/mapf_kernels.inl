@@ -3191,16 +3191,28 @@ __device__ __forceinline__ uint32_t dpp_get(uint32_t v) {
 }
 template <int LPE>
 __device__ __forceinline__ void group_xchg(const uint32_t v, uint32_t (&o)[LPE - 1]) {
-    static_assert(LPE == 4 || LPE == 8, "DPP exchange is written for groups of 4 or 8 lanes");
+    static_assert(LPE == 4 || LPE == 8 || LPE == 16, "DPP exchange is written for groups of 4, 8 or 16 lanes (one DPP row)");
     o[0] = dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]: lane ^ 1
     o[1] = dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]: lane ^ 2
     o[2] = dpp_get<0x1B>(v);  // quad_perm [3,2,1,0]: lane ^ 3
-    if constexpr (LPE == 8) {
+    if constexpr (LPE >= 8) {
         const uint32_t m = dpp_get<0x141>(v);  // row_half_mirror: lane ^ 7
         o[6] = m;
         o[5] = dpp_get<0xB1>(m);  // lane ^ 6
         o[4] = dpp_get<0x4E>(m);  // lane ^ 5
         o[3] = dpp_get<0x1B>(m);  // lane ^ 4
+    }
+    if constexpr (LPE == 16) {
+        const uint32_t r = dpp_get<0x140>(v);  // row_mirror: lane ^ 15
+        o[14] = r;
+        o[13] = dpp_get<0xB1>(r);  // lane ^ 14
+        o[12] = dpp_get<0x4E>(r);  // lane ^ 13
+        o[11] = dpp_get<0x1B>(r);  // lane ^ 12
+        const uint32_t h = dpp_get<0x141>(r);  // (lane ^ 7) ^ 15 = lane ^ 8
+        o[7] = h;
+        o[8] = dpp_get<0xB1>(h);   // lane ^ 9
+        o[9] = dpp_get<0x4E>(h);   // lane ^ 10
+        o[10] = dpp_get<0x1B>(h);  // lane ^ 11
     }
 }
 
@@ -3211,7 +3223,7 @@ __device__ __forceinline__ void group_xchg(const uint32_t v, uint32_t (&o)[LPE -
 // contender got in (MA-env:502-526 is sequential; dependencies only point to lower indices).
 template <int J, int LPE>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {  // lane J of every lane group
-    constexpr int pattern = (J << 5) | (LPE == 8 ? 0x18 : 0x1C);  // bit mode: lane' = (lane & and_mask) | or_mask
+    constexpr int pattern = (J << 5) | (LPE == 16 ? 0x10 : (LPE == 8 ? 0x18 : 0x1C));  // bit mode: lane' = (lane & and_mask) | or_mask
     return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, pattern);
 }
 template <int LPE>
@@ -3596,7 +3608,11 @@ __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const
     const uint32_t tgt = want ? (uint32_t)(((int)old + (dr << 8) + dc) & 0xFFFF) : kNoCell;
     MAPF_STAMP(16);
     uint32_t cur = old;
-    if (__any(want)) cur = resolve_moves_dpp<LPE>(a, old, tgt);
+    if (__any(want)) {
+        if constexpr (LPE <= 8) cur = resolve_moves_dpp<LPE>(a, old, tgt);
+        else cur = resolve_moves<K, LPE>(p, reinterpret_cast<uint2 *>(l.tab + grp * LPE), lane, a, old, tgt);  // (16 lanes: the LDS
+            // table and two ballots per round; replaying sixteen decisions on DPP-exchanged words is the longer chain)
+    }
     MAPF_STAMP(2);
     // ---- publish the moves: x old | new << 16, y goal | new << 16 (the aux wave reads the new cell there), z the
     //      placement slot word; how the step ends every wave decides for itself (decide_end) ----
@@ -3629,7 +3645,7 @@ __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const
 template <class K, int LPE, int MW, int WPS = 0>
 __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS,
                                                                 const IoTail tail) {
-    static_assert(K::kSlicedDraw, "k_step3 is for the specialised finite shapes with full groups of 4 or 8 lanes");
+    static_assert(K::kSlicedDraw, "k_step3 is for finite shapes with the sliced draw: full groups of 4, 8 or 16 lanes");
     MAPF_STAMP_ENTRY();
     const Params &p = *pp;
     const Io io = MAPF_IO_JOIN;
@@ -4362,6 +4378,8 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
 #define MAPF_SPECIALIZATIONS(X) X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)
 #elif defined(MAPF_DEV_C5)
 #define MAPF_SPECIALIZATIONS(X) X(3, 64, 2, (kFlagsHeadline | MAPF_FLAG_LIFELONG), 8, 16, 2, 1, 64)
+#elif defined(MAPF_DEV_N16)
+#define MAPF_SPECIALIZATIONS(X) X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)
 #elif defined(MAPF_SMALL_SHAPES)  // the checking build
 #define MAPF_SPECIALIZATIONS(X)                 \
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)   \
@@ -4382,7 +4400,7 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
 // object.  (Harmless and kept; the difference it was meant to remove -- the same kernel slower when compiled at creation
 // than prebuilt -- turned out to be the compiler version of the process's hiprtc, DESIGN.md 4 "Run-time specialisation";
 // the full library and a library holding this kernel alone measure the same within the tool's 0.7 %.)
-#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5) && !defined(MAPF_DEV_CTE)
+#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5) && !defined(MAPF_DEV_CTE) && !defined(MAPF_DEV_N16)
 template __global__ void k_step3<KFixed<8, 2, kFlagsHeadline, 8, 16, 2, 1>, 8, 32, 0>(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);
 #endif
 

@@ -57,6 +57,9 @@
 #elif defined(MAPF_DEV_CTE)  // (development: the single-agent env at 8 and 64 lanes per env)
 #define MAPF_FOR_LPE(X) X(8) X(64)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
+#elif defined(MAPF_DEV_N16)  // (development: groups of 16 lanes, 7 x 7 windows: the reference's training setup)
+#define MAPF_FOR_LPE(X) X(16)
+#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 64>(__VA_ARGS__);
 #elif defined(MAPF_DEV_C5)  // (development: the c5 shape only -- one wavefront per env, 5 x 5 windows)
 #define MAPF_FOR_LPE(X) X(64)
 #define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
@@ -229,7 +232,7 @@ constexpr int mask_width_for(int sr) {
 // small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
 template <class K, int LPE, int MW>
 hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
-    if constexpr (K::kSlicedDraw && LPE <= 8) {
+    if constexpr (K::kSlicedDraw && LPE <= 16) {
         if (e->three_wave)
             LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(192), e->lds_bytes, s, e->d_params,
                            IO_HEAD_ARGS(io));
@@ -726,6 +729,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (lpe != 64 || c.sensor_range > 2 || cte)
         return fail(nullptr, MAPF_ERR_CONFIG, "this development build only holds 64-lane groups with windows up to 5 x 5");
 #endif
+#if defined(MAPF_DEV_N16)
+    if (lpe != 16 || c.sensor_range != 3 || cte)
+        return fail(nullptr, MAPF_ERR_CONFIG, "this development build only holds 16-lane groups with 7 x 7 windows");
+#endif
 #if defined(MAPF_DEV_C3) || defined(MAPF_SMALL_SHAPES)
     if ((lpe != 4 && lpe != 8) || c.sensor_range > 2 || cte)
         return fail(nullptr, MAPF_ERR_CONFIG, "this reduced build (development / checking) only holds groups of 4 and 8 lanes with windows up to 5 x 5");
@@ -767,8 +774,8 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // SIMD with three waves per workgroup (beyond that the two-wave kernel's 128-register build is the one that fits)
         e->many_dense = (int64_t)e->blocks * (many_threads(lpe) / 64) > (int64_t)2 * 4 * cus;
         if (const char *f = getenv("MAPF_FORCE_DENSE")) e->many_dense = atoi(f) != 0;
-        e->three_wave = sliced && lpe <= 8 && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
-        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && lpe <= 8 && atoi(f) != 0;  // test / A-B knob
+        e->three_wave = sliced && lpe <= 16 && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
+        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && lpe <= 16 && atoi(f) != 0;  // test / A-B knob
         if (e->three_wave) e->dense = 0;
     };
     // (round 3) the runtime-config kernels of such shapes take the sliced draw as well: MAPF_RT_SLICED=0 keeps them on the
