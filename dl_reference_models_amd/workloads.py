@@ -22,6 +22,10 @@ WORKLOADS = {
     "c2_1024x16x16_n4": (1024, 16, 16, 4, 0.20, {}),
     "c3_8192x32x32_n8": (8192, 32, 32, 8, 0.40, {}),
     "c5_1024x64x64_n64_lifelong": (1024, 64, 64, 64, 0.20, {"lifelong_mapf": True, "steps_per_episode": 256}),
+    # not a BASELINE.json config: the env settings of the reference's own training run (/root/reference/main.py:55-67:
+    # 16 agents, sensor_range 3, no action mask in the observation) on synthetic 32x32 grids, for the secondary numbers
+    "ref_training_4096x32x32_n16": (4096, 32, 32, 16, 0.20, {"sensor_range": 3, "include_action_mask_in_obs": False,
+                                                              "steps_per_episode": 256}),
 }
 HEADLINE = "c3_8192x32x32_n8"  # BASELINE.json metric: agent-steps/sec at 8192 envs x 8 agents on 32x32
 

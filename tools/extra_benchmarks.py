@@ -152,3 +152,5 @@ if __name__ == "__main__":
     run("c3_8192x32x32_n8", stagger=True, tag="c3 with staggered episodes (some env resets in every step)")
     run("c2_1024x16x16_n4")
     run("c5_1024x64x64_n64_lifelong")
+    run("ref_training_4096x32x32_n16", tag="the reference's training setup (main.py: 16 agents, 7x7 windows), 4096 envs")
+    run("ref_training_4096x32x32_n16", stagger=True, tag="the reference's training setup, staggered episodes")
