@@ -17,9 +17,16 @@ that number.  `value_synchronised` is the same run with all episodes in phase (r
 All K timed launches are hipGraph replays (graphs of min(K, --graph-steps) launches plus one for the
 remainder) unless --graph-steps 0.
 
-Rank 0 prints ONE JSON line.  Extra fields: `roofline` (algorithmic bytes / measured kernel time vs the
-8 TB/s HBM peak), `cpu_baseline` (the parity-checked C restatement, oracle/, one thread) and
+Rank 0 prints ONE JSON line.  Extra fields: `roofline` -- `frac` is SURVEY 8(d)'s quantity computed from the `value`
+next to it (agent-steps/s x algorithmic bytes per agent-step / 8 TB/s), `frac_kernel` the same bytes over the DEVICE
+time of the timed launches (HIP events), `traffic` the PMC-counted HBM bytes per launch from profiles/hbm_traffic.json --,
+`per_call_ms` / `python_api_ms_per_step` (the step without a captured graph: plain C-ABI launches, and
+VecReferenceModel.step() in a Python loop), `cpu_baseline` (the parity-checked C restatement, oracle/, one thread) and
 `cpu_baseline_all_cores` (one env shard per host thread) -- reported baselines, not targets.
+
+`--workload` selects any entry of dl_reference_models_amd.workloads.WORKLOADS (c2, c3, c5, the reference's training
+setup, the single-agent env), `--fused T` the T-steps-per-launch kernels: every number in DESIGN.md's evidence table is
+one `bench.py` command, so that rocprofv3 can be put in front of it (tools/collect_evidence.sh).
 """
 
 from __future__ import annotations
@@ -60,6 +67,12 @@ def parse_args(argv=None):
                          "'synchronised' is asked for")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target duration of each CPU baseline leg")
+    ap.add_argument("--fused", type=int, default=0,
+                    help="T > 0: launches of T env steps each (mapf_step_many / mapf_cte_step_many, observation written "
+                         "every step) instead of one step per launch; --steps and --warmup stay in env steps")
+    ap.add_argument("--api-steps", type=int, default=200,
+                    help="env steps of the two secondary legs per_call_ms (plain C-ABI launches, no graph) and "
+                         "python_api_ms_per_step (VecReferenceModel.step in a Python loop); 0 = skip them")
     ap.add_argument("--kernel-samples", type=int, default=200,
                     help="launches timed one by one with events (isolated launch duration)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -241,31 +254,43 @@ def _oracle_shard(name, env_ids, stagger):
     from dl_reference_models_amd import workloads as wl
 
     cfg = wl.workload_config(name, env_ids)
+    spe = int(cfg["steps_per_episode"])
+    if wl.is_single_agent(name):
+        batch = orc.OracleCteBatch(cfg["grid"], cfg, seeds=cfg["seeds"])
+        batch.reset()
+        if stagger:
+            batch.set_step_counts([int(i) % spe for i in env_ids])
+        return batch, cfg
     batch = orc.OracleBatch(cfg["grid"], cfg, seeds=cfg["seeds"])
     batch.reset()
     if stagger:
         for i, e in zip(env_ids, batch.envs):
-            e.step_count = int(i) % int(cfg["steps_per_episode"])
+            e.step_count = int(i) % spe
     return batch, cfg
 
 
 def _oracle_run(batch, acts, steps):
+    if hasattr(batch, "run"):  # (single-agent env: the whole loop is one C call)
+        batch.run(acts, steps)
+        return
     for t in range(steps):
         batch.step(acts[t % acts.shape[0]], auto_reset=True, outputs=True)
 
 
-def cpu_baselines(name, env_ids, action_pool, seconds):
+def cpu_baselines(name, env_ids, action_pool, seconds, stagger):
     """The C oracle (CPU restatement, parity-checked against the reference) on a bounded sample of the same
-    workload (same grids, seeds, actions, staggered episode phases): one thread, then one env shard per thread."""
+    workload (same grids, seeds, actions, episode phases): one thread, then one env shard per thread.  No thread is
+    pinned: the shards run on whatever cores the scheduler gives the process (the usable count is in `sample`)."""
     from concurrent.futures import ThreadPoolExecutor
 
     res = {}
     n_cpu = os.cpu_count()
-    # ---- one thread: a 1024-env sample, step count sized from a short probe
+    phases = "staggered episodes" if stagger else "episodes in phase"
+    # ---- one thread: a sample of up to 1024 envs, step count sized from a short probe
     ids1 = list(env_ids[:1024])
-    batch, cfg = _oracle_shard(name, ids1, True)
+    batch, cfg = _oracle_shard(name, ids1, stagger)
     n = cfg["num_agents"]
-    acts = action_pool[:, : len(ids1), :]
+    acts = np.ascontiguousarray(action_pool[:, : len(ids1), :])
     t0 = time.perf_counter()
     _oracle_run(batch, acts, 10)
     probe = (time.perf_counter() - t0) / 10
@@ -275,8 +300,8 @@ def cpu_baselines(name, env_ids, action_pool, seconds):
     dt = time.perf_counter() - t0
     res["cpu_baseline"] = {
         "value": len(ids1) * n * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{len(ids1)} envs x {steps} steps of the same workload (staggered episodes), C restatement "
-                  f"(oracle/), 1 thread of {n_cpu} host cpus",
+        "sample": f"{len(ids1)} envs x {steps} steps of the same workload ({phases}), C restatement "
+                  f"(oracle/), 1 thread of {n_cpu} host cpus, not pinned",
     }
     # ---- all cores: one shard of the batch per thread (the C step loop runs outside the GIL)
     threads = min(host_threads(), 128)
@@ -286,7 +311,7 @@ def cpu_baselines(name, env_ids, action_pool, seconds):
         ids = list(env_ids[k * per:(k + 1) * per])
         if ids:
             shards.append((ids, k * per))
-    made = [(_oracle_shard(name, ids, True)[0], action_pool[:, off:off + len(ids), :]) for ids, off in shards]
+    made = [(_oracle_shard(name, ids, stagger)[0], np.ascontiguousarray(action_pool[:, off:off + len(ids), :])) for ids, off in shards]
     steps_mt = int(min(max(seconds / max(probe * per / len(ids1), 1e-6), 20), 5000))
     with ThreadPoolExecutor(len(made)) as ex:
         t0 = time.perf_counter()
@@ -295,10 +320,163 @@ def cpu_baselines(name, env_ids, action_pool, seconds):
     total = sum(b.B for b, _ in made)
     res["cpu_baseline_all_cores"] = {
         "value": total * n * steps_mt / dt, "unit": "agent-steps/s", "cores": len(made), "kind": "port",
-        "sample": f"{total} envs x {steps_mt} steps, one shard of {per} envs per thread, {len(made)} threads "
+        "sample": f"{total} envs x {steps_mt} steps, one shard of {per} envs per thread, {len(made)} threads, not pinned "
                   f"(os.cpu_count() = {n_cpu}, usable = {host_threads()})",
     }
     return res
+
+
+# ------------------------------------------------------------------------------------------------------
+# what is launched: one of four runners behind the same few calls
+# ------------------------------------------------------------------------------------------------------
+class _MultiAgentRunner:
+    """mapf_step (one env step per launch) or mapf_step_many (--fused T: T env steps per launch, observation every step)."""
+
+    def __init__(self, name, env_ids, device, rank, args):
+        import torch
+
+        from dl_reference_models_amd import workloads as wl
+        from dl_reference_models_amd.vec_env import VecReferenceModel
+
+        self.torch = torch
+        _b, self.h, self.w, self.n, self.density, _ = wl.WORKLOADS[name]
+        self.env_ids = env_ids
+        self.b = len(env_ids)
+        cfg = wl.workload_config(name, env_ids)
+        cfg["device"] = str(device)
+        self.cfg = cfg
+        self.env = VecReferenceModel(cfg)
+        self.spe = int(cfg["steps_per_episode"])
+        self.lifelong = bool(cfg.get("lifelong_mapf", False))
+        self.obs_len = self.env.obs_len
+        self.T = int(args.fused)
+        self.steps_per_launch = self.T or 1
+        self.bytes_per_env_step = wl.algorithmic_bytes_per_env_step(self.n, self.obs_len, self.h, self.w)
+        # what a fused launch really moves per env-step: the action byte, the observation row and the per-step outputs
+        # (state, rows and counters stay in registers / LDS for the T steps)
+        self.bytes_moved_per_env_step = (self.n * (1 + 4 * self.obs_len + 4 + 2) + 2 + 4 * 14) if self.T else None
+        # actions: uniform over {0..4}, generated once and resident in HBM (inputs, not part of the path)
+        self.pool = (2 * self.T) if self.T else (max(args.graph_steps, 1) if args.graph_steps else 128)
+        self.action_pool_np = np.random.default_rng(999 + rank).integers(0, 5, size=(self.pool, self.b, self.n)).astype(np.int8)
+        self.action_pool = torch.from_numpy(self.action_pool_np).to(device)
+        self._base, self._stride = self.action_pool.data_ptr(), self.b * self.n
+        info = self.env.launch_info()
+        self.kernel = "k_step_many" if self.T else ("k_step3" if info["threads"] == 192 else "k_step")
+        if self.T:
+            B, N, Lo, T = self.b, self.n, self.obs_len, self.T
+            from dl_reference_models_amd import _lib as L
+            self._out = [torch.empty((T, B, N, Lo), dtype=torch.float32, device=device),
+                         torch.empty((T, B, N), dtype=torch.float32, device=device),
+                         torch.empty((T, B), dtype=torch.uint8, device=device), torch.empty((T, B), dtype=torch.uint8, device=device),
+                         torch.empty((T, B, L.INFO_ALL), dtype=torch.float32, device=device),
+                         torch.empty((T, B, N, 2), dtype=torch.uint8, device=device)]
+            self._out_ptrs = [t.data_ptr() for t in self._out]
+
+    def launch(self, i, sptr):
+        if not self.T:
+            return self.env.step_raw(self._base + (i % self.pool) * self._stride, sptr, 1)
+        o = self._out_ptrs
+        return self.env._lib.mapf_step_many(self.env._h, self.T, self._base + (i % 2) * self.T * self._stride, o[0], 2, o[1],
+                                            o[2], o[3], o[4], o[5], sptr)
+
+    def python_call(self, i):
+        """The same launch through the public Python API (tensor in, dict of tensors out)."""
+        if not self.T:
+            return self.env.step(self.action_pool[i % self.pool])
+        k = (i % 2) * self.T
+        return self.env.step_many(self.action_pool[k:k + self.T], obs_mode=2)
+
+    def set_phases(self, staggered):
+        from dl_reference_models_amd import _lib as L
+
+        self.env.reset()
+        if staggered:  # env with global index i is i mod steps_per_episode steps into its episode
+            c = self.env.get_state()["counters"]
+            c[:, L.CTR_STEP_COUNT] = np.asarray(self.env_ids, dtype=np.int64) % self.spe
+            self.env.set_state(counters=c)
+
+    def episodes_device(self, out):
+        self.env.episode_sums_device(out)
+
+    def episode_sums(self):
+        return self.env.episode_sums()
+
+    def poll_error(self):
+        self.env.poll_error()
+
+    def launch_info(self):
+        return self.env.launch_info()
+
+
+class _SingleAgentRunner:
+    """The single-agent (CTE) sibling env: mapf_cte_step / mapf_cte_step_many."""
+
+    def __init__(self, name, env_ids, device, rank, args):
+        import torch
+
+        from dl_reference_models_amd import workloads as wl
+        from dl_reference_models_amd.vec_env_single_agent import VecSingleAgentReferenceModel
+
+        self.torch = torch
+        _b, self.h, self.w, self.n, self.density, _ = wl.WORKLOADS[name]
+        self.env_ids = env_ids
+        self.b = len(env_ids)
+        cfg = wl.workload_config(name, env_ids)
+        cfg["device"] = str(device)
+        self.cfg = cfg
+        self.env = VecSingleAgentReferenceModel(cfg)
+        self.spe = int(cfg["steps_per_episode"])
+        self.lifelong = False
+        self.obs_len = self.env.obs_len
+        self.T = int(args.fused)
+        self.steps_per_launch = self.T or 1
+        self.bytes_per_env_step = wl.cte_algorithmic_bytes_per_env_step(self.n, self.h, self.w)
+        self.bytes_moved_per_env_step = (4 * self.obs_len + self.n + 8 + 2 + 16) if self.T else None
+        self.pool = (2 * self.T) if self.T else (max(args.graph_steps, 1) if args.graph_steps else 128)
+        self.action_pool_np = np.random.default_rng(999 + rank).integers(0, 5, size=(self.pool, self.b, self.n)).astype(np.int8)
+        self.action_pool = torch.from_numpy(self.action_pool_np).to(device)
+        self.kernel = "k_cte_step"
+        if self.T:
+            B, T = self.b, self.T
+            self._out = [torch.empty((T, B, self.obs_len), dtype=torch.float32, device=device),
+                         torch.empty((T, B), dtype=torch.float64, device=device),
+                         torch.empty((T, B), dtype=torch.uint8, device=device), torch.empty((T, B), dtype=torch.uint8, device=device),
+                         torch.empty((T, B, 4), dtype=torch.float32, device=device)]
+            self._out_ptrs = [t.data_ptr() for t in self._out]
+
+    def launch(self, i, sptr):
+        e = self.env
+        stride = self.b * self.n
+        if not self.T:
+            return e._lib.mapf_cte_step(e._h, self.action_pool.data_ptr() + (i % self.pool) * stride, e._obs.data_ptr(),
+                                        e._reward.data_ptr(), e._terminated.data_ptr(), e._truncated.data_ptr(),
+                                        e._info.data_ptr(), None, 1, sptr)
+        o = self._out_ptrs
+        return e._lib.mapf_cte_step_many(e._h, self.T, self.action_pool.data_ptr() + (i % 2) * self.T * stride, o[0], 2, o[1],
+                                         o[2], o[3], o[4], sptr)
+
+    def python_call(self, i):
+        if not self.T:
+            return self.env.step(self.action_pool[i % self.pool])
+        k = (i % 2) * self.T
+        return self.env.step_many(self.action_pool[k:k + self.T], obs_mode=2)
+
+    def set_phases(self, staggered):
+        self.env.reset()
+        if staggered:
+            self.env.set_step_counts(np.asarray(self.env_ids, dtype=np.int64) % self.spe)
+
+    def episodes_device(self, out):  # (this env keeps no episode statistics on the device)
+        return None
+
+    def episode_sums(self):
+        return None
+
+    def poll_error(self):
+        self.env.poll_error()
+
+    def launch_info(self):
+        return self.env.launch_info()
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -310,7 +488,7 @@ def worker(args) -> int:
 
     from dl_reference_models_amd import _lib as L
     from dl_reference_models_amd import sharding, workloads as wl
-    from dl_reference_models_amd.vec_env import VecReferenceModel, metrics_from_sums
+    from dl_reference_models_amd.vec_env import metrics_from_sums
 
     rank, local_rank, world = sharding.dist_env()
     if world != args.gpus:
@@ -338,30 +516,20 @@ def worker(args) -> int:
         env_ids = list(sharding.weak_range(b_weak, rank))
         total_envs = b_weak * world
     b_per = len(env_ids)
-    cfg = wl.workload_config(name, env_ids)
-    cfg["device"] = str(device)
-    if os.environ.get("MAPF_JIT_PREBUILT_TOO"):  # development A/B: step kernels compiled from the source tree's mapf_kernels.inl
-        cfg["jit_specialize"] = True
-    if os.environ.get("MAPF_SEPARATE_OUTPUTS"):  # A/B knob of VecReferenceModel (output tensors in separate allocations)
-        cfg["separate_output_tensors"] = True
-    env = VecReferenceModel(cfg)
-    L_obs = env.obs_len
-    spe = int(cfg["steps_per_episode"])
-
-    # actions: uniform over {0..4}, generated once and resident in HBM (inputs, not part of the path)
-    pool = max(args.graph_steps, 1) if args.graph_steps else 128
-    action_pool_np = np.random.default_rng(999 + rank).integers(0, 5, size=(pool, b_per, n)).astype(np.int8)
-    action_pool = torch.from_numpy(action_pool_np).to(device)
+    run = (_SingleAgentRunner if wl.is_single_agent(name) else _MultiAgentRunner)(name, env_ids, device, rank, args)
+    spl = run.steps_per_launch
+    if args.steps % spl or args.warmup % spl:
+        raise SystemExit(f"--fused {spl}: --steps and --warmup must be multiples of it")
+    spe = run.spe
     stream = torch.cuda.current_stream(device)
     sptr = stream.cuda_stream
-    step_raw = env.step_raw
-    base, stride = action_pool.data_ptr(), b_per * n
 
-    def run_plain(k, ptr=sptr):
-        for t in range(k):
-            rc = step_raw(base + (t % pool) * stride, ptr, 1)
+    def run_plain(k, ptr=sptr, first=0):
+        """k launches through the C ABI (k * spl env steps)."""
+        for i in range(first, first + k):
+            rc = run.launch(i, ptr)
             if rc != 0:
-                raise RuntimeError(f"mapf_step failed: {rc}")
+                raise RuntimeError(f"launch failed: {rc}")
 
     graphs = {}  # launches per graph -> captured graph
 
@@ -374,7 +542,8 @@ def worker(args) -> int:
             graphs[k] = g
         return graphs[k]
 
-    G = min(args.graph_steps, max(args.steps, 1)) if args.graph_steps > 0 else 0
+    launches = args.steps // spl
+    G = min(args.graph_steps, max(launches, 1)) if args.graph_steps > 0 else 0
 
     def plan(k):
         """(graph, replays) pairs that make exactly k launches."""
@@ -383,7 +552,7 @@ def worker(args) -> int:
         full, rem = divmod(k, G)
         return ([(graph_of(G), full)] if full else []) + ([(graph_of(rem), 1)] if rem else [])
 
-    def run_steps(k, pl):
+    def run_launches(k, pl):
         if G == 0:
             run_plain(k)
         else:
@@ -396,25 +565,18 @@ def worker(args) -> int:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def set_phases(staggered):
-        env.reset()
-        if staggered:  # env with global index i is i mod steps_per_episode steps into its episode
-            c = env.get_state()["counters"]
-            c[:, L.CTR_STEP_COUNT] = np.asarray(env_ids, dtype=np.int64) % spe
-            env.set_state(counters=c)
-
     def timed_region(staggered):
-        set_phases(staggered)
+        run.set_phases(staggered)
         run_plain(3)  # code object resident before any capture
         torch.cuda.synchronize(device)
-        pl_w, pl_t = plan(args.warmup), plan(args.steps)  # capture happens here, outside the timed region
         # pre-roll (state preparation, like the reset above; not warmup and not timed; reported in config): by
         # default one episode length of steps straight before the warmup, so that a SHORT timed window (the driver's
         # --steps 20 is 0.12 ms of GPU time) sees the steady state of a long run -- every env has been through a reset
         # since its phase was set, the placements of the episodes ending in the window have been pre-drawn in the
         # background -- and a GPU that has been busy, instead of the start-up transient after the idle of the capture
         pre = args.pre_roll if args.pre_roll >= 0 else spe
-        pl_p = plan(pre)
+        pre_l = (pre + spl - 1) // spl
+        pl_w, pl_t, pl_p = plan(args.warmup // spl), plan(launches), plan(pre_l)  # capture happens here, outside the timed region
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(stream)  # (torch creates the HIP event at its first record: not inside the timed region)
         ev1.record(stream)
@@ -425,23 +587,23 @@ def worker(args) -> int:
         # the region.  (Round 3: the host-side read that used to sit here -- 393 KB over PCIe plus a sum -- left the GPU
         # idle for a millisecond, and a 20-launch window that starts on a GPU idle for >= 1 ms takes 138 us instead of
         # 122: tools/idle_gap.py.  It is the warm-up's job to have the GPU warm when the clock starts.)
-        run_steps(pre, pl_p)
-        run_steps(args.warmup, pl_w)
+        run_launches(pre_l, pl_p)
+        run_launches(args.warmup // spl, pl_w)
         with torch.cuda.stream(stream):
-            env.episode_sums_device(ep_before)
+            run.episodes_device(ep_before)
         fence()
         t0 = time.perf_counter()
         ev0.record(stream)
-        run_steps(args.steps, pl_t)
+        run_launches(launches, pl_t)
         ev1.record(stream)
         fence()
         elapsed = time.perf_counter() - t0
         # HIP events on the launch stream over the timed region: device time per launch (graph replays leave no
-        # host gap).  This is the roofline's kernel time.
-        kernel_ms = ev0.elapsed_time(ev1) / args.steps
-        env.poll_error()
-        ep0 = int(ep_before[L.ACC_EPISODES].item())
-        resets = int(env.episode_sums()[L.ACC_EPISODES]) - ep0
+        # host gap).  This is the kernel time of roofline.frac_kernel.
+        kernel_ms = ev0.elapsed_time(ev1) / launches
+        run.poll_error()
+        sums = run.episode_sums()
+        resets = None if sums is None else int(sums[L.ACC_EPISODES]) - int(ep_before[L.ACC_EPISODES].item())
         per_rank = [elapsed]
         if use_dist:
             tt = torch.zeros(world, dtype=torch.float64, device=None if args.share_gpu else device)
@@ -458,12 +620,36 @@ def worker(args) -> int:
         legs["synchronised"] = timed_region(False)
     head = legs["staggered"] if "staggered" in legs else legs["synchronised"]
 
+    # ---- secondary legs, same state as the last timed region left (what a caller that does NOT capture a graph pays) ----
+    # per_call_ms: plain launches through the C ABI, back to back, fence to fence (the host's launch rate or the GPU's
+    # step time, whichever is slower); python_api_ms_per_step: the same through VecReferenceModel.step() -- argument
+    # checks, ctypes marshalling, the dict of output tensors -- i.e. what a Python RL loop pays per env step before its
+    # policy has run.  Both per ENV STEP (a fused launch counts its T steps).
+    per_call_ms = python_api_ms = None
+    if args.api_steps > 0:
+        k = max(args.api_steps // spl, 1)
+        run_plain(min(k, 8))
+        fence()
+        t0 = time.perf_counter()
+        run_plain(k)
+        fence()
+        per_call_ms = 1e3 * (time.perf_counter() - t0) / (k * spl)
+        for i in range(min(k, 8)):
+            run.python_call(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(k):
+            run.python_call(i)
+        fence()
+        python_api_ms = 1e3 * (time.perf_counter() - t0) / (k * spl)
+        run.poll_error()
+
     # ---- secondary: event pairs around single launches (includes ~2 us of event/launch overhead) ----
     samples = []
-    for i in range(args.kernel_samples):
+    for i in range(args.kernel_samples if spl == 1 else 0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        step_raw(base + (i % pool) * stride, sptr, 1)
+        run.launch(i, sptr)
         e1.record(stream)
         samples.append((e0, e1))
     torch.cuda.synchronize(device)
@@ -472,27 +658,40 @@ def worker(args) -> int:
 
     # off the timed path: episode statistics accumulated on the device, summed over ranks with ONE small
     # all-reduce (96 bytes; latency-bound, so one fused buffer; RCCL on GPUs)
-    sums = sharding.all_reduce_stats(env.episode_sums().astype(np.float64),
-                                     device=device if (use_dist and not args.share_gpu) else None)
-    episode_metrics = metrics_from_sums(sums, n, bool(cfg.get("lifelong_mapf", False)))
+    sums = run.episode_sums()
+    episode_metrics = None
+    if sums is not None:
+        sums = sharding.all_reduce_stats(sums.astype(np.float64), device=device if (use_dist and not args.share_gpu) else None)
+        episode_metrics = metrics_from_sums(sums, n, run.lifelong)
 
     agent_steps = total_envs * n * args.steps
-    bytes_per_launch = wl.algorithmic_bytes_per_env_step(n, L_obs, h, w) * b_per
-    achieved = bytes_per_launch / (head["kernel_ms"] * 1e-3) / 1e9
+    value = agent_steps / head["elapsed"]
+    # Roofline: roofline.frac = agent_steps_per_s x algorithmic bytes per agent-step / 8 TB/s, on the `value`
+    # this line reports, per GPU.  frac_kernel is the same bytes over the DEVICE time of the timed launches (HIP events on
+    # the launch stream, no host-side cost): what the kernel itself reaches; rocprofv3's per-kernel average under
+    # profiles/ is to be compared with kernel_ms.
+    bytes_env_step = run.bytes_per_env_step
+    bytes_per_launch = bytes_env_step * b_per * spl
+    achieved = (value / world) * (bytes_env_step / n) / 1e9
+    achieved_kernel = bytes_per_launch / (head["kernel_ms"] * 1e-3) / 1e9
+    key = name + (f"+fused{spl}" if spl > 1 else "")
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile) and b_per == b_weak:
         try:
-            traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tfile)).get(key, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
 
-    full, rem = divmod(args.steps, G) if G else (0, 0)
+    full, rem = divmod(launches, G) if G else (0, 0)
     launch = (f"hipGraph: {full} x {G} launches" + (f" + 1 x {rem}" if rem else "")) if G else "plain launches"
+    if spl > 1:
+        launch += f", {spl} env steps per launch (fused, observation written every step)"
+    phases = "staggered" if "staggered" in legs else "synchronised"
     result = {
-        "metric": "agent-steps/sec at 8192 envs x 8 agents on 32x32 grid" if (name == wl.HEADLINE and b_per == b_weak)
-        else f"agent-steps/sec ({name}, {b_per} envs per GPU)",
-        "value": agent_steps / head["elapsed"],
+        "metric": "agent-steps/sec at 8192 envs x 8 agents on 32x32 grid" if (name == wl.HEADLINE and b_per == b_weak and spl == 1)
+        else f"agent-steps/sec ({key}, {b_per} envs per GPU)",
+        "value": value,
         "unit": "agent-steps/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -504,32 +703,43 @@ def worker(args) -> int:
         "dtype": "u8/i16 state, f32 observations",
         "data": "synthetic",
         "config": {
-            "workload": name, "envs_per_gpu": b_per, "total_envs": total_envs, "grid": [h, w], "agents": n,
-            "obstacle_density": density, "obs_floats": L_obs, "sensor_range": cfg["sensor_range"],
-            "steps_per_episode": spe, "lock_metrics": True, "auto_reset": "in-kernel",
-            "episode_phases": "staggered" if "staggered" in legs else "synchronised",
-            "resets_in_timed_region": head["resets"],
+            "workload": key, "envs_per_gpu": b_per, "total_envs": total_envs, "grid": [h, w], "agents": n,
+            "obstacle_density": density, "obs_floats": run.obs_len, "sensor_range": run.cfg.get("sensor_range"),
+            "steps_per_episode": spe, "lock_metrics": not wl.is_single_agent(name), "auto_reset": "in-kernel",
+            "episode_phases": phases, "resets_in_timed_region": head["resets"],
             "pre_roll_steps": args.pre_roll if args.pre_roll >= 0 else spe,
-            "actions": "uniform{0..4}, device-resident", "launch": launch,
-            "parallelism": f"env-sharded x{world}, no hot-path collective", **env.launch_info(),
+            "actions": "uniform{0..4}, device-resident", "launch": launch, "env_steps_per_launch": spl,
+            "parallelism": f"env-sharded x{world}, no hot-path collective", **run.launch_info(),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": "profiles/hbm_traffic.json (rocprofv3 PMC passes of this kernel, committed; not measured in this run)" if traffic else None,
-            "kernel": "k_step", "kernel_ms": head["kernel_ms"], "isolated_launch_ms": isolated_launch_ms,
-            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "definition": "frac = value / n_gpus x algorithmic bytes per agent-step / peak (SURVEY 8(d)); "
+                          "frac_kernel = algorithmic bytes per launch / kernel_ms (HIP events over the timed launches) / peak",
+            "kernel": run.kernel, "kernel_ms": head["kernel_ms"], "achieved_kernel": achieved_kernel,
+            "frac_kernel": achieved_kernel / HBM_PEAK_GBS, "isolated_launch_ms": isolated_launch_ms,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_bytes_per_agent_step": bytes_env_step / n,
         },
-        "episodes_finished": float(sums[L.ACC_EPISODES]),
+        "per_call_ms": per_call_ms,
+        "python_api_ms_per_step": python_api_ms,
+        "episodes_finished": None if sums is None else float(sums[L.ACC_EPISODES]),
         "episode_metrics": episode_metrics,
     }
+    if run.bytes_moved_per_env_step:
+        moved = run.bytes_moved_per_env_step * b_per * spl
+        result["roofline"]["bytes_moved_per_launch"] = moved
+        result["roofline"]["frac_kernel_on_bytes_moved"] = moved / (head["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if wl.is_single_agent(name):
+        result["env_steps_per_s"] = value / n
     if "synchronised" in legs and "staggered" in legs:
         s = legs["synchronised"]
         result["value_synchronised"] = agent_steps / s["elapsed"]
         result["ms_per_step_synchronised"] = 1e3 * s["elapsed"] / args.steps
         result["resets_in_timed_region_synchronised"] = s["resets"]
         result["roofline"]["kernel_ms_synchronised"] = s["kernel_ms"]
-        result["roofline"]["frac_synchronised"] = bytes_per_launch / (s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        result["roofline"]["frac_synchronised"] = (agent_steps / s["elapsed"] / world) * (bytes_env_step / n) / 1e9 / HBM_PEAK_GBS
+        result["roofline"]["frac_kernel_synchronised"] = bytes_per_launch / (s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     if world > 1:
         result["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in head["per_rank"]]
         result["config"]["rank0_cpus"] = len(rank_cpus) if rank_cpus else None
@@ -537,7 +747,7 @@ def worker(args) -> int:
         result["shared_gpu"] = True
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result.update(cpu_baselines(name, env_ids, action_pool_np, args.cpu_seconds))
+            result.update(cpu_baselines(name, env_ids, run.action_pool_np, args.cpu_seconds, phases == "staggered"))
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

@@ -29,6 +29,9 @@ FLAG_LIFELONG = 16
 FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
 FLAG_SINGLE_AGENT = 256
+FLAG_SAMPLER_WORKGROUPS = 0x02000000
+FLAG_FORCE_SPARSE = 0x04000000
+FLAG_FORCE_DENSE = 0x08000000
 FLAG_JIT_SPECIALIZE = 0x10000000
 FLAG_SEQUENTIAL_RESET = 0x20000000
 FLAG_NO_CELL_MAP = 0x40000000
@@ -50,7 +53,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_get_episode_stats", "mapf_episode_stats_async", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
+    "mapf_step", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_assign_new_goal", "mapf_get_episode_stats", "mapf_episode_stats_async", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
 )
 
 
@@ -164,6 +167,8 @@ def load():
     L.mapf_cte_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.mapf_observe.restype = C.c_int
     L.mapf_observe.argtypes = [vp, vp, vp]
+    L.mapf_assign_new_goal.restype = C.c_int
+    L.mapf_assign_new_goal.argtypes = [vp, i32, i32, vp, vp]
     L.mapf_get_episode_stats.restype = C.c_int
     L.mapf_get_episode_stats.argtypes = [vp, vp, i32]
     L.mapf_episode_stats_async.restype = C.c_int

@@ -4396,12 +4396,4 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
     X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)  /* the reference's own training setup, main.py:55-67: 16 agents, 7x7 */
 #endif
 
-// The headline kernel is instantiated HERE, ahead of everything the host dispatchers instantiate: it then leads the code
-// object.  (Harmless and kept; the difference it was meant to remove -- the same kernel slower when compiled at creation
-// than prebuilt -- turned out to be the compiler version of the process's hiprtc, DESIGN.md 4 "Run-time specialisation";
-// the full library and a library holding this kernel alone measure the same within the tool's 0.7 %.)
-#if !defined(MAPF_NS_IS_JIT) && !defined(MAPF_DEV_C5) && !defined(MAPF_DEV_CTE) && !defined(MAPF_DEV_N16)
-template __global__ void k_step3<KFixed<8, 2, kFlagsHeadline, 8, 16, 2, 1>, 8, 32, 0>(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);
-#endif
-
 }  // namespace

@@ -44,35 +44,9 @@
 #include <string>
 #include <vector>
 
-#include "mapf_step.h"
+#include "mapf_engine.h"  // mapf_step.h, the device code (mapf_kernels.inl, namespace mapfk) and the launch units' entry points
 
-#include "mapf_kernels.inl"
-
-// Group widths and window-mask widths the dispatchers below instantiate.  -DMAPF_DEV_C3 (development builds only: the
-// library is then good for the c3 shape and nothing else) cuts them to what the headline shape needs, so that an edit of
-// the step kernel can be compiled in under a minute instead of several.
-#if defined(MAPF_DEV_C3)
-#define MAPF_FOR_LPE(X) X(8)
-#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
-#elif defined(MAPF_DEV_CTE)  // (development: the single-agent env at 8 and 64 lanes per env)
-#define MAPF_FOR_LPE(X) X(8) X(64)
-#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
-#elif defined(MAPF_DEV_N16)  // (development: groups of 16 lanes, 7 x 7 windows: the reference's training setup)
-#define MAPF_FOR_LPE(X) X(16)
-#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 64>(__VA_ARGS__);
-#elif defined(MAPF_DEV_C5)  // (development: the c5 shape only -- one wavefront per env, 5 x 5 windows)
-#define MAPF_FOR_LPE(X) X(64)
-#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
-#elif defined(MAPF_SMALL_SHAPES)  // (the checking build: groups of 4 and 8 lanes, windows up to 5 x 5)
-#define MAPF_FOR_LPE(X) X(4) X(8)
-#define MAPF_MW_DISPATCH(e, F, L, ...) return F<L, 32>(__VA_ARGS__);
-#else
-#define MAPF_FOR_LPE(X) X(4) X(8) X(16) X(32) X(64)
-#define MAPF_MW_DISPATCH(e, F, L, ...)                     \
-    if ((e)->mask_w == 32) return F<L, 32>(__VA_ARGS__);   \
-    if ((e)->mask_w == 64) return F<L, 64>(__VA_ARGS__);   \
-    return F<L, 128>(__VA_ARGS__);
-#endif
+using namespace mapfk;
 
 namespace {
 
@@ -166,15 +140,17 @@ struct DeviceScope {
             return fail((e), MAPF_ERR_HIP, std::string("kernel launch failed: ") + hipGetErrorString(_s)); \
     } while (0)
 
-// Status of the launch just made.  hipGetLastError() also returns (and clears) an error some earlier, unrelated call
-// left on this thread (torch, RCCL, an event query), so stale state is dropped right before the launch and only what
-// the launch itself raised is reported.
-#define LAUNCH_CHECKED(...)                          \
-    do {                                             \
-        (void)hipGetLastError();                     \
-        hipLaunchKernelGGL(__VA_ARGS__);             \
-        return hipGetLastError();                    \
-    } while (0)
+// engine knobs of mapf_config.flags that choose among builds of the same kernel (never part of the env's configuration)
+constexpr uint32_t kKernelChoiceFlags = MAPF_FLAG_FORCE_DENSE | MAPF_FLAG_FORCE_SPARSE | MAPF_FLAG_SAMPLER_WORKGROUPS;
+
+// Development builds only (-DMAPF_DEV): knobs read from the environment for A/B timing.  The shipped library reads
+// MAPF_JIT_CACHE_DIR (and the usual XDG / HOME variables behind it) and nothing else: which kernel a handle runs is a
+// function of its mapf_config alone.
+#ifdef MAPF_DEV
+const char *dev_env(const char *name) { return getenv(name); }
+#else
+constexpr const char *dev_env(const char *) { return nullptr; }
+#endif
 
 int pick_lpe(int n) {
     int l = 4;
@@ -182,38 +158,10 @@ int pick_lpe(int n) {
     return l;
 }
 
-enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };
-
-// the step kernels take the head of Io as individual (preloadable) arguments
-#define IO_HEAD_ARGS(io) (io).agents, (io).scal, (io).grid_rows, (io).actions, (io).B, (io).H, (io).W, (io).bn8, \
-                         static_cast<const IoTail &>(io)
-
-template <class K, int LPE, int MW>
-hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s);
-
-template <int LPE, int MW>
-hipError_t launch_kind(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
-    if (kind == KIND_STEP) {
-        if constexpr (LPE <= 16) {
-            if (e->rt_sliced) return launch_fixed_step<KRuntimeSliced, LPE, MW>(e, io, s);
-        }
-        if constexpr (LPE < 32) {  // both register budgets, as for the specialised kernels (launch_fixed_step)
-            if (e->dense)
-                LAUNCH_CHECKED((k_step<KRuntime, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
-                               e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
-        }
-        LAUNCH_CHECKED((k_step<KRuntime, LPE, MW>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)),
-                       e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io));
-    }
-    if (kind == KIND_RESET)
-        LAUNCH_CHECKED((k_reset<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
-    LAUNCH_CHECKED((k_observe<KRuntime, LPE, MW>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
-}
-
 // the step kernel compiled for one of the BASELINE.json shapes (MAPF_SPECIALIZATIONS), if the config matches
 int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) return 0;
-    const uint32_t cfg_flags = c.flags & ~(MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_SEQUENTIAL_RESET | MAPF_FLAG_JIT_SPECIALIZE);
+    const uint32_t cfg_flags = c.flags & ~(MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_SEQUENTIAL_RESET | MAPF_FLAG_JIT_SPECIALIZE | kKernelChoiceFlags);
 #define MAPF_MATCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                            \
     if (c.num_agents == N_ && c.sensor_range == SR_ && cfg_flags == (uint32_t)(FLAGS_) &&                             \
         c.deadlock_window_steps == DW_ && c.livelock_window_steps == LW_ && nearby_clamped == NEARBY_ &&           \
@@ -224,48 +172,17 @@ int match_specialization(const mapf_config &c, int lpe, int nearby_clamped) {
     return 0;
 }
 
-// observation-window mask width of a sensor range (what mapf_create computes into mask_w)
-constexpr int mask_width_for(int sr) {
-    return (2 * sr + 1) * (2 * sr + 1) <= 32 ? 32 : ((2 * sr + 1) * (2 * sr + 1) <= 64 ? 64 : 128);
-}
-
-// small groups: both register budgets are built (k_step's WPS), the engine says which one its grid needs
-template <class K, int LPE, int MW>
-hipError_t launch_fixed_step(const mapf_engine *e, const Io &io, hipStream_t s) {
-    if constexpr (K::kSlicedDraw && LPE <= 16) {
-        if (e->three_wave)
-            LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(192), e->lds_bytes, s, e->d_params,
-                           IO_HEAD_ARGS(io));
-    }
-    if constexpr (LPE < 32) {
-        if (e->dense)
-            LAUNCH_CHECKED((k_step<K, LPE, MW, 4>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
-                           e->d_params, IO_HEAD_ARGS(io));
-    }
-    LAUNCH_CHECKED((k_step<K, LPE, MW, 0>), dim3(e->blocks + e->sampler_blocks), dim3(step_threads(LPE)), e->lds_bytes, s,
-                   e->d_params, IO_HEAD_ARGS(io));
-}
-
-hipError_t launch_specialized_step(const mapf_engine *e, const Io &io, hipStream_t s) {
-    switch (e->special) {
-#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_) \
-    case ID:                                                            \
-        return launch_fixed_step<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_)>(e, io, s);
-        MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
-#undef MAPF_LAUNCH
-    }
-    return hipErrorInvalidValue;
-}
-
-template <int LPE, int MW>
-hipError_t launch_many_t(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
-    if constexpr (LPE < 32) {  // both register budgets, as for k_step
-        if (e->many_dense)
-            LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW, 4>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s,
-                           e->d_params, IO_HEAD_ARGS(io), T, obs_mode, pol);
-    }
-    LAUNCH_CHECKED((k_step_many<KRuntime, LPE, MW>), dim3(e->blocks), dim3(many_threads(LPE)), e->lds_bytes, s, e->d_params,
-                   IO_HEAD_ARGS(io), T, obs_mode, pol);
+LaunchPlan plan_of(const mapf_engine *e) {
+    LaunchPlan lp;
+    lp.d_params = e->d_params;
+    lp.blocks = e->blocks;
+    lp.sampler_blocks = e->sampler_blocks;
+    lp.lds_bytes = e->lds_bytes;
+    lp.dense = e->dense;
+    lp.many_dense = e->many_dense;
+    lp.three_wave = e->three_wave;
+    lp.rt_sliced = e->rt_sliced;
+    return lp;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -294,6 +211,7 @@ struct Hiprtc {
                             // ROCm, not the toolkit this library was built with: on this image clang 20 (ROCm 7.0) against
                             // clang 22 (7.2), which is the whole difference between a kernel compiled at creation and the
                             // same kernel prebuilt ("Run-time specialisation")
+    std::string build_id;   // path : size : mtime of the library file (part of the on-disk cache key)
     bool ok = false;
 };
 const Hiprtc &hiprtc_api() {
@@ -323,6 +241,12 @@ const Hiprtc &hiprtc_api() {
         h.version = reinterpret_cast<int (*)(int *, int *)>(dlsym(h.lib, "hiprtcVersion"));
         int major = 0, minor = 0;
         if (h.version && h.version(&major, &minor) == 0) h.ver = std::to_string(major) + "." + std::to_string(minor);
+        // hiprtcVersion() stops at major.minor; the library file's identity (path, size, modification time) tells patch
+        // levels and rebuilt toolchains apart for the on-disk cache
+        Dl_info info;
+        struct stat st;
+        if (dladdr(reinterpret_cast<void *>(h.create), &info) && info.dli_fname && stat(info.dli_fname, &st) == 0)
+            h.build_id = std::string(info.dli_fname) + ":" + std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtime);
     });
     return h;
 }
@@ -364,9 +288,16 @@ static std::string slurp(const std::string &path) {
     std::ifstream f(path, std::ios::binary);
     return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
-static void mkdirs(const std::string &dir) {  // best effort (like `mkdir -p`)
+static void mkdirs(const std::string &dir) {  // best effort (like `mkdir -p`), private to the user
     for (size_t k = 1; k <= dir.size(); k++)
-        if (k == dir.size() || dir[k] == '/') (void)mkdir(dir.substr(0, k).c_str(), 0777);
+        if (k == dir.size() || dir[k] == '/') (void)mkdir(dir.substr(0, k).c_str(), 0700);
+}
+// The cache holds executable code objects: it is only read from / written to a directory (and files) that belong to
+// this user and that nobody else can write to.
+static bool private_to_user(const std::string &path) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
 // Tries to give `e` step kernels compiled for its configuration; on any failure e->jit_note says why.
@@ -377,10 +308,9 @@ void jit_specialize(mapf_engine *e) {
     if (c.flags & MAPF_FLAG_GENERIC_KERNEL) { e->jit_note = "MAPF_FLAG_GENERIC_KERNEL is set"; return; }
     // (MAPF_JIT_PREBUILT_TOO: development knob -- compile even when a prebuilt specialisation matches, so that an edited
     //  mapf_kernels.inl can be timed against the library's own kernels without rebuilding the library)
-    if (e->special && !getenv("MAPF_JIT_PREBUILT_TOO")) { e->jit_note = "a prebuilt specialisation matches"; return; }
+    if (e->special && !dev_env("MAPF_JIT_PREBUILT_TOO")) { e->jit_note = "a prebuilt specialisation matches"; return; }
     if (lpe != pick_lpe(N)) { e->jit_note = "lanes_per_env overrides the group width"; return; }
     if (N > 16 && !e->use_map) { e->jit_note = "wide group without the LDS cell map"; return; }
-    if (getenv("MAPF_JIT_FORCE_FAIL")) { e->jit_note = "MAPF_JIT_FORCE_FAIL is set (test knob)"; return; }
     const Hiprtc &rt = hiprtc_api();
     if (!rt.ok) { e->jit_note = "libhiprtc.so could not be loaded"; return; }
     const std::string dir = library_dir();
@@ -398,7 +328,7 @@ void jit_specialize(mapf_engine *e) {
     const std::string step_expr = std::string("mapfjit::") + step_kernel + "<mapfjit::" + inst + tail_ + ", " + std::to_string(wps) + ">";
     const int many_wps = (lpe < 32 && e->many_dense) ? 4 : 0;
     const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ", " + std::to_string(many_wps) + ">";
-    const std::string key = std::to_string(c.device) + "|" + step_expr;
+    const std::string key = std::to_string(c.device) + "|" + step_expr + "|" + many_expr;  // (the module holds both kernels)
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(key);
     if (it == g_jit_cache.end()) {
@@ -410,16 +340,21 @@ void jit_specialize(mapf_engine *e) {
             arch = arch.substr(0, arch.find(':'));
         }
         // ---- the on-disk cache first
-        const std::string cdir = jit_cache_dir();
+        std::string cdir = jit_cache_dir();
         std::string cfile;
+        if (!cdir.empty()) {
+            mkdirs(cdir);
+            if (!private_to_user(cdir)) cdir.clear();  // (someone else's or a world-writable directory: no cache)
+        }
         if (!cdir.empty()) {
             uint64_t h = fnv1a(slurp(dir + "/mapf_kernels.inl"));
             h = fnv1a(slurp(dir + "/../../include/mapf_step.h"), h);
-            h = fnv1a(step_expr + "|" + many_expr + "|" + arch + "|O3 c++17 kernarg-preload-16 v2|hiprtc " + rt.ver, h);
+            h = fnv1a(step_expr + "|" + many_expr + "|" + arch + "|O3 c++17 kernarg-preload-16 v2|hiprtc " + rt.ver + "|" + rt.build_id, h);
             char name[40];
             snprintf(name, sizeof name, "/%016llx", (unsigned long long)h);
             cfile = cdir + name;
-            const std::string code = slurp(cfile + ".co"), names = slurp(cfile + ".names");
+            const bool trusted = private_to_user(cfile + ".co") && private_to_user(cfile + ".names");
+            const std::string code = trusted ? slurp(cfile + ".co") : std::string(), names = trusted ? slurp(cfile + ".names") : std::string();
             const size_t nl = names.find('\n');
             if (!code.empty() && nl != std::string::npos) {
                 JitModule m;
@@ -479,7 +414,6 @@ void jit_specialize(mapf_engine *e) {
         }
         m.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!cfile.empty() && !step_sym.empty() && !many_sym.empty()) {  // best effort: write to a temporary name, then rename
-            mkdirs(cdir);
             const std::string tmp = cfile + ".tmp" + std::to_string((long)getpid());
             std::ofstream fc(tmp + ".co", std::ios::binary), fn(tmp + ".names");
             fc.write(code.data(), (std::streamsize)code.size());
@@ -519,39 +453,44 @@ hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mo
     return hipModuleLaunchKernel(e->jit_many, e->blocks, 1, 1, many_threads(e->lpe), 1, 1, e->lds_bytes, s, args, nullptr);
 }
 
+// Which launch unit serves a handle: the prebuilt specialisation it matched, else the runtime-config kernels of its group
+// width and window-mask width (mapf_launch.hip; a reduced build only declares -- and links -- the units it holds, and
+// mapf_create has refused every configuration outside them).
+#define MAPF_RUNTIME_CASE(L, MW) \
+    if (e->lpe == L && e->mask_w == MW) return MAPF_RUNTIME_CALL(L, MW);
+#define MAPF_RUNTIME_CASES(L) MAPF_FOR_MW(MAPF_RUNTIME_CASE, L)
+
 hipError_t dispatch_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
     if (e->jit_many) return launch_jit_many(e, io, T, obs_mode, pol, s);
+    const LaunchPlan lp = plan_of(e);
     switch (e->special) {
-#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_)                                             \
-    case ID:                                                                                                        \
-        if constexpr (LPE_ < 32) {                                                                                  \
-            if (e->many_dense)                                                                                      \
-                LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_), 4>), \
-                               dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T, \
-                               obs_mode, pol);                                                                      \
-        }                                                                                                           \
-        LAUNCH_CHECKED((k_step_many<KFixed<N_, SR_, (uint32_t)(FLAGS_), DW_, LW_, NEARBY_, MINN_>, LPE_, mask_width_for(SR_)>), \
-                       dim3(e->blocks), dim3(many_threads(LPE_)), e->lds_bytes, s, e->d_params, IO_HEAD_ARGS(io), T,   \
-                       obs_mode, pol);
+#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_) \
+    case ID:                                                            \
+        return launch_special_many_##ID(lp, io, T, obs_mode, pol, s);
         MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
 #undef MAPF_LAUNCH
     }
-#define MAPF_CASE(L) \
-    case L:          \
-        MAPF_MW_DISPATCH(e, launch_many_t, L, e, io, T, obs_mode, pol, s)
-    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
-#undef MAPF_CASE
+#define MAPF_RUNTIME_CALL(L, MW) launch_runtime_many_##L##_##MW(lp, io, T, obs_mode, pol, s)
+    MAPF_FOR_LPE(MAPF_RUNTIME_CASES)
+#undef MAPF_RUNTIME_CALL
     return hipErrorInvalidValue;
 }
 
 hipError_t dispatch(int kind, const mapf_engine *e, const Io &io, hipStream_t s) {
     if (kind == KIND_STEP && e->jit_step) return launch_jit_step(e, io, s);
-    if (kind == KIND_STEP && e->special) return launch_specialized_step(e, io, s);
-#define MAPF_CASE(L) \
-    case L:          \
-        MAPF_MW_DISPATCH(e, launch_kind, L, kind, e, io, s)
-    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
-#undef MAPF_CASE
+    const LaunchPlan lp = plan_of(e);
+    if (kind == KIND_STEP) {
+        switch (e->special) {
+#define MAPF_LAUNCH(ID, N_, SR_, FLAGS_, DW_, LW_, NEARBY_, MINN_, LPE_) \
+    case ID:                                                            \
+        return launch_special_step_##ID(lp, io, s);
+            MAPF_SPECIALIZATIONS(MAPF_LAUNCH)
+#undef MAPF_LAUNCH
+        }
+    }
+#define MAPF_RUNTIME_CALL(L, MW) launch_runtime_##L##_##MW(kind, lp, io, s)
+    MAPF_FOR_LPE(MAPF_RUNTIME_CASES)
+#undef MAPF_RUNTIME_CALL
     return hipErrorInvalidValue;
 }
 
@@ -563,27 +502,31 @@ static int alloc_device_state(mapf_engine *e);
 static hipError_t invalidate_slots(mapf_engine *e) {
     return hipMemset(e->p.next_sg, 0xFF, (size_t)e->p.B * e->p.N * sizeof(uint32_t));
 }
-// A pending (staged or valid) slot means: the env's stream array already holds the state AFTER the background draw and the
-// visible state sits in vis_rng (mapf_kernels.inl: kSlotInvalid).  Voiding such a slot without replacing the stream
-// (mapf_set_grids does: the free-cell tables changed, the stream did not) must put the visible state back, or the env
-// would silently skip one rng.choice draw.
-static int restore_visible_streams(mapf_engine *e) {
-    const int B = e->p.B, N = e->p.N;
-    HIP_TRY(e, hipDeviceSynchronize());
-    std::vector<uint32_t> slots((size_t)B * N);
-    std::vector<uint64_t> vis((size_t)B * 6), rng((size_t)B * 6);
-    HIP_TRY(e, hipMemcpy(slots.data(), e->p.next_sg, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(vis.data(), e->d_vis_rng, vis.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(e, hipMemcpy(rng.data(), e->d_rng, rng.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    bool any = false;
-    for (int b = 0; b < B; b++) {
-        if (slots[(size_t)b * N] != kSlotInvalid) {
-            memcpy(rng.data() + (size_t)b * 6, vis.data() + (size_t)b * 6, 6 * sizeof(uint64_t));
-            any = true;
-        }
-    }
-    if (any) HIP_TRY(e, hipMemcpy(e->d_rng, rng.data(), rng.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    return MAPF_OK;
+// What mapf_set_grids has to put right on the device once the new rows are there, one thread per agent:
+//  * a pending (staged or valid) slot means that the env's stream array already holds the state AFTER the background draw
+//    and the visible state sits in vis_rng (mapf_kernels.inl: kSlotInvalid).  Voiding such a slot without replacing the
+//    stream (the free-cell tables changed, the stream did not) must put the visible state back, or the env would silently
+//    skip one rng.choice draw;
+//  * the agents' pass bits are a function of the grid (agent_pass_bits: which neighbours of the position can be stepped on).
+// (Until round 4 both were host loops over downloaded copies of the slots, the streams and all four agent planes.)
+static __global__ __launch_bounds__(256) void k_after_set_grids(uint2 *__restrict__ hot, const uint64_t *__restrict__ rows, int B, int N, int H,
+                                                          int W, int col_pad, const uint32_t *__restrict__ slots,
+                                                          const uint64_t *__restrict__ vis, uint64_t *__restrict__ rng) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= B * N) return;
+    const int env = i / N, a = i - env * N;
+    if (a == 0 && slots[(size_t)env * N] != kSlotInvalid)
+        for (int k = 0; k < 6; k++) rng[(size_t)env * 6 + k] = vis[(size_t)env * 6 + k];
+    uint2 w = hot[i];
+    const int r = (int)((w.x >> 8) & 255u), c = (int)(w.x & 255u);
+    const uint64_t *my = rows + (size_t)env * H;
+    auto blocked = [&](int rr, int cc) -> uint32_t {
+        if (rr < 0 || rr >= H || cc < 0 || cc >= W) return 1u;
+        return (uint32_t)((my[rr] >> (cc + col_pad)) & 1ull);
+    };
+    const uint32_t pass = (blocked(r - 1, c) | (blocked(r, c + 1) << 1) | (blocked(r + 1, c) << 2) | (blocked(r, c - 1) << 3)) ^ 15u;
+    w.y = (w.y & 0x00FFFFFFu) | (pass << 24);
+    hot[i] = w;
 }
 // After host writes to positions / goals / counters the MAY_FINISH hint of the last step is stale: force it on
 // (conservative: the sampler skips the env for one step, the next step writes the real hint).
@@ -769,19 +712,20 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         // more than three waves per SIMD in one launch of the step kernel?  (k_step's WPS; 4 SIMDs per compute unit)
         const int64_t waves = (int64_t)(e->blocks + e->sampler_blocks) * (step_threads(lpe) / 64);
         e->dense = waves > (int64_t)3 * 4 * cus;
-        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->dense = atoi(f) != 0;  // test knob: either build on any grid
+        if (c.flags & MAPF_FLAG_FORCE_DENSE) e->dense = 1;  // engine knobs (tests): either build on any grid
+        if (c.flags & MAPF_FLAG_FORCE_SPARSE) e->dense = 0;
         // k_step3 (state / observation / aux wave): the sliced-draw shapes, while a launch has at most three waves per
         // SIMD with three waves per workgroup (beyond that the two-wave kernel's 128-register build is the one that fits)
         e->many_dense = (int64_t)e->blocks * (many_threads(lpe) / 64) > (int64_t)2 * 4 * cus;
-        if (const char *f = getenv("MAPF_FORCE_DENSE")) e->many_dense = atoi(f) != 0;
+        if (c.flags & MAPF_FLAG_FORCE_DENSE) e->many_dense = 1;
+        if (c.flags & MAPF_FLAG_FORCE_SPARSE) e->many_dense = 0;
         e->three_wave = sliced && lpe <= 16 && (int64_t)e->blocks * 3 <= (int64_t)3 * 4 * cus && !e->dense;
-        if (const char *f = getenv("MAPF_THREE_WAVE")) e->three_wave = sliced && lpe <= 16 && atoi(f) != 0;  // test / A-B knob
+        if (const char *f = dev_env("MAPF_THREE_WAVE")) e->three_wave = sliced && lpe <= 16 && atoi(f) != 0;  // (-DMAPF_DEV: A/B)
         if (e->three_wave) e->dense = 0;
     };
-    // (round 3) the runtime-config kernels of such shapes take the sliced draw as well: MAPF_RT_SLICED=0 keeps them on the
-    // sampler workgroups (A/B and test knob)
-    const char *rts = getenv("MAPF_RT_SLICED");
-    const bool rt_sliced = small_full && finite_sampled && !special_id && !(rts && atoi(rts) == 0);
+    // (round 3) the runtime-config kernels of such shapes take the sliced draw as well; MAPF_FLAG_SAMPLER_WORKGROUPS keeps
+    // them on the sampler workgroups (engine knob: tests run both)
+    const bool rt_sliced = small_full && finite_sampled && !special_id && !(c.flags & MAPF_FLAG_SAMPLER_WORKGROUPS);
     e->rt_sliced = rt_sliced && !jit_sliced;
     plan_grid(small_full && finite_sampled && (special_id != 0 || jit_sliced || rt_sliced));
 
@@ -792,7 +736,7 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.V = 2 * c.sensor_range + 1;
     p.L = mapf_obs_len(&c);
     p.steps_per_episode = c.steps_per_episode;
-    p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_JIT_SPECIALIZE);
+    p.flags = c.flags & ~(MAPF_FLAG_GENERIC_KERNEL | MAPF_FLAG_NO_CELL_MAP | MAPF_FLAG_JIT_SPECIALIZE | kKernelChoiceFlags);
     e->special = special_id;
     p.dw = c.deadlock_window_steps;
     p.lw = c.livelock_window_steps;
@@ -915,14 +859,14 @@ static int alloc_device_state(mapf_engine *e) {
     HIP_TRY(e, hipMalloc(&e->d_rows, (size_t)B * H * sizeof(uint64_t)));
     HIP_TRY(e, hipMalloc(&e->d_free_cells, (size_t)B * p.HW * sizeof(uint16_t)));
     HIP_TRY(e, hipMalloc(&e->d_free_rank, (size_t)B * p.HW * sizeof(uint16_t)));
-    HIP_TRY(e, hipMalloc(&e->d_err, 4 * sizeof(int)));
+    HIP_TRY(e, hipMalloc(&e->d_err, 8 * sizeof(int)));  // [0..3] the latched error record, [4..6] mapf_assign_new_goal's result
     HIP_TRY(e, hipMemset(e->d_agents, 0, agent_state_bytes(e->bn8)));
     HIP_TRY(e, hipMemset(e->d_scal, 0, scal_bytes));
     HIP_TRY(e, hipMemset(reinterpret_cast<char *>(e->d_scal) + scal_bytes, 0xFF, slot_bytes));  // kSlotInvalid
     HIP_TRY(e, hipMemset(e->d_vis_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
     HIP_TRY(e, hipMemset(e->d_ring, 0, BN * p.ring_stride * sizeof(int16_t)));
     HIP_TRY(e, hipMemset(e->d_rng, 0, (size_t)B * 6 * sizeof(uint64_t)));
-    HIP_TRY(e, hipMemset(e->d_err, 0, 4 * sizeof(int)));
+    HIP_TRY(e, hipMemset(e->d_err, 0, 8 * sizeof(int)));
     HIP_TRY(e, hipMalloc(&e->d_ep_acc, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
     HIP_TRY(e, hipMemset(e->d_ep_acc, 0, (size_t)B * MAPF_NUM_EPISODE_ACC * sizeof(int)));
     p.ep_acc = e->d_ep_acc;
@@ -990,24 +934,21 @@ int mapf_set_grids(mapf_handle e, const uint8_t *grids, int32_t shared) {
         }
     }
     ON_DEVICE(e);
-    {
-        const int rc = restore_visible_streams(e);  // (synchronises the device first)
-        if (rc != MAPF_OK) return rc;
-    }
+    HIP_TRY(e, hipDeviceSynchronize());  // (no launch of this handle may still be reading the tables that change below)
     HIP_TRY(e, hipMemcpy(e->d_rows, rows.data(), rows.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_cells, cells.data(), cells.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_free_rank, rank.data(), rank.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->d_n_free, nfree.data(), nfree.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(e, invalidate_slots(e));
     e->h_rows = rows;
     e->grids_set = true;
-    {   // the agents' pass bits are a function of the grid (upload_agents recomputes them)
-        HIP_TRY(e, hipDeviceSynchronize());
-        std::vector<AgentRec> recs;
-        int rc = download_agents(e, recs);
-        if (rc == MAPF_OK) rc = upload_agents(e, recs);
-        if (rc != MAPF_OK) return rc;
-    }
+    // visible streams back under the slots that are about to be voided, pass bits of every agent for the new rows: on
+    // the device, stream-ordered behind the copies above (k_after_set_grids), then the slots
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_after_set_grids, dim3((unsigned)(((size_t)B * N + 255) / 256)), dim3(256), 0, (hipStream_t)0, e->d_agents,
+                       e->d_rows, B, N, H, W, e->col_pad, e->p.next_sg, e->d_vis_rng, e->d_rng);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, invalidate_slots(e));
+    HIP_TRY(e, hipDeviceSynchronize());
     return MAPF_OK;
 }
 
@@ -1383,13 +1324,14 @@ static CteIo make_cte_io(const mapf_engine *e) {
 }
 
 static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s, CteMany many = CteMany{1, 2}) {
-#define MAPF_CASE(L)                                                                                                 \
-    case L:                                                                                                          \
-        if (step && many.T > 1) LAUNCH_CHECKED((k_cte_step<L, true>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io, many); \
-        if (step) LAUNCH_CHECKED((k_cte_step<L, false>), dim3(e->blocks), dim3(128), e->lds_bytes, s, e->d_params, io, many); \
-        LAUNCH_CHECKED((k_cte_reset<L>), dim3(e->blocks), dim3(64), e->lds_bytes, s, e->d_params, io);
+#ifndef MAPF_NO_CTE_KERNELS
+    const LaunchPlan lp = plan_of(e);
+#define MAPF_CASE(L) \
+    case L:          \
+        return launch_cte_##L(lp, io, step, s, many);
     switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -1481,6 +1423,77 @@ int mapf_observe(mapf_handle e, float *obs, void *stream) {
     io.obs = obs;
     ON_DEVICE(e);
     LAUNCH_TRY(e, dispatch(KIND_OBSERVE, e, io, (hipStream_t)stream));
+    return MAPF_OK;
+}
+
+namespace {
+// _assign_new_goal (MA-env:284-304) for ONE agent of ONE env, outside step(): the old goal is cleared, the candidates are the
+// free cells (row-major, _free_positions) that hold no agent and no other agent's goal, r = rng.integers(k) on the env's
+// stream (no draw when k == 1), new goal = r-th candidate.  One thread: this is the reference's per-call helper, not the
+// hot path (inside step() the respawn runs in the step kernels, in agent order).  out: {status, row, col}.
+__global__ __launch_bounds__(64) void k_assign_new_goal(uint2 *__restrict__ hot, const Params *__restrict__ pp, int env, int agent,
+                                                         int *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const Params &p = *pp;
+    const int N = p.N, F = p.n_free[env];
+    uint2 *rec = hot + (size_t)env * N;
+    const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+    auto is_candidate = [&](uint32_t cell) {
+        for (int b = 0; b < N; b++) {
+            const uint32_t w0 = rec[b].x;
+            if ((w0 & 0xFFFFu) == cell) return false;               // occupied (the agent's own cell included, :292)
+            if (b != agent && (w0 >> 16) == cell) return false;     // somebody else's goal (the own old goal was cleared, :288)
+        }
+        return true;
+    };
+    int k = 0;
+    for (int f = 0; f < F; f++) k += is_candidate(fc[f]) ? 1 : 0;
+    if (k == 0) {
+        raise_error(p, MAPF_ERR_NO_RESPAWN, env, agent, 0);
+        out[0] = MAPF_ERR_NO_RESPAWN;
+        return;
+    }
+    // the env's VISIBLE stream: while a pre-drawn placement is pending it sits in vis_rng (mapf_kernels.inl: kSlotInvalid);
+    // that placement was drawn from a state this call leaves behind, so it is voided
+    uint32_t *slots = p.next_sg + (size_t)env * N;
+    const bool pending = slots[0] != kSlotInvalid;
+    Pcg g;
+    pcg_load(g, (pending ? p.vis_rng : p.rng) + (size_t)env * 6);
+    bool stuck = false;
+    const uint32_t r = pcg_bounded(g, (uint32_t)(k - 1), stuck);
+    if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, agent, 0);
+    pcg_store(g, p.rng + (size_t)env * 6);
+    if (pending)
+        for (int b = 0; b < N; b++) slots[b] = kSlotInvalid;
+    uint32_t left = r, cell = 0;
+    for (int f = 0; f < F; f++) {
+        if (!is_candidate(fc[f])) continue;
+        if (left == 0) { cell = fc[f]; break; }
+        left--;
+    }
+    rec[agent].x = (rec[agent].x & 0xFFFFu) | (cell << 16);
+    out[0] = MAPF_OK;
+    out[1] = (int)(cell >> 8);
+    out[2] = (int)(cell & 255u);
+}
+}  // namespace
+
+int mapf_assign_new_goal(mapf_handle e, int32_t env, int32_t agent, int16_t *new_goal, void *stream) {
+    if (!e || !new_goal) return fail(e, MAPF_ERR_CONFIG, "null argument");
+    if (e->cte) return fail(e, MAPF_ERR_STATE, "mapf_assign_new_goal is not available for the single-agent variant");
+    if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_assign_new_goal");
+    if (env < 0 || env >= e->p.B || agent < 0 || agent >= e->p.N) return fail(e, MAPF_ERR_CONFIG, "env / agent index out of range");
+    ON_DEVICE(e);
+    int *d_out = e->d_err + 4;  // (three ints behind the error record, same allocation)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_assign_new_goal, dim3(1), dim3(64), 0, (hipStream_t)stream, e->d_agents, e->d_params, (int)env, (int)agent, d_out);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    int res[3] = {0, 0, 0};
+    HIP_TRY(e, hipMemcpy(res, d_out, sizeof res, hipMemcpyDeviceToHost));
+    if (res[0] != MAPF_OK) return fail(e, res[0], "No valid cell available for lifelong goal reassignment.");
+    new_goal[0] = (int16_t)res[1];
+    new_goal[1] = (int16_t)res[2];
     return MAPF_OK;
 }
 

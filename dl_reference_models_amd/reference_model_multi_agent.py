@@ -11,8 +11,9 @@ State arrays (``_positions_arr`` ...) are host mirrors: they are refreshed from 
 every ``reset``/``step`` and pushed back to the device before the next call when a caller has
 modified them (that is how the reference's tests inject states).
 
-Not provided: matplotlib rendering (``render`` is a no-op; GUI is out of scope) and monkeypatching
-``_assign_new_goal`` (the respawn runs inside the kernel).
+``_assign_new_goal(agent_idx)`` is callable by itself (one respawn on the device, the env's stream advances as in
+the reference); monkeypatching it does not reach the respawns ``step()`` performs, which run inside the kernel.
+Not provided: matplotlib rendering (``render`` is a no-op; GUI is out of scope).
 
 The dict API costs a kernel launch plus small device<->host copies per call, like any per-env
 Python env; throughput work should use ``VecReferenceModel`` (tensor API) instead.
@@ -280,6 +281,14 @@ class ReferenceModel(MultiAgentEnv):
         np.copyto(self._completed_once_arr, flags[1])
         np.copyto(self._blocking_pressure_prev_arr, flags[2])
         self._push_if_dirty()
+
+    def _assign_new_goal(self, agent_idx: int) -> np.ndarray:
+        """MA-env:284-304: assign a new unique, currently unoccupied goal to one agent (device-side: the candidates in
+        row-major order, ``rng.integers(k)`` on the env's PCG64 stream).  Returns the new goal like the reference."""
+        self._push_if_dirty()
+        new_goal = self._engine.assign_new_goal(0, int(agent_idx)).astype(self._coord_dtype, copy=False)
+        self._pull()
+        return new_goal
 
     def get_agent_ids(self):
         return set(self.agents)

@@ -99,6 +99,18 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_JIT_SPECIALIZE
     if cfg.get("force_generic_kernel", False):  # engine knob: skip the compile-time specialised step kernel
         f |= L.FLAG_GENERIC_KERNEL
+    # engine knobs (tests): which build of the small-group step kernels -- "dense" = the 128-register one mapf_create
+    # otherwise picks for grids of more than three waves per SIMD, "sparse" = never that one; and where the
+    # runtime-config kernels pre-draw placements ("sampler_workgroups" instead of slices in the env workgroups)
+    budget = cfg.get("register_budget")
+    if budget not in (None, "dense", "sparse"):
+        raise ValueError(f"register_budget must be None, 'dense' or 'sparse', got {budget!r}")
+    if budget == "dense":
+        f |= L.FLAG_FORCE_DENSE
+    if budget == "sparse":
+        f |= L.FLAG_FORCE_SPARSE
+    if cfg.get("background_draw") == "sampler_workgroups":
+        f |= L.FLAG_SAMPLER_WORKGROUPS
     return f
 
 
@@ -202,6 +214,19 @@ class VecReferenceModel:
         else:
             # the reference ctor draws one generate_starts_goals() (MA-env:133-134): same RNG consumption
             self._check(self._lib.mapf_reset(h, None, None, self._stream()))
+
+    def set_grids(self, grid) -> None:
+        """New obstacle grids for the handle's envs ([H,W] shared or [num_envs,H,W]; same shape as at creation), e.g. per
+        curriculum stage.  State, streams and counters stay; pre-drawn placements are voided (their free-cell tables
+        changed) and the agents' pass bits follow the new rows.  Positions must lie on free cells of the new grids before
+        the next step (reset, or set_state)."""
+        grid = np.ascontiguousarray(grid, dtype=np.uint8)
+        shared = 1 if grid.ndim == 2 else 0
+        g = grid[None] if shared else grid
+        if g.shape[1:] != self.grid_shape or (not shared and g.shape[0] != self.num_envs):
+            raise ValueError("grid must be [H,W] or [num_envs,H,W] with the handle's H, W")
+        self._check(self._lib.mapf_set_grids(self._h, g.ctypes.data_as(C.c_void_p), shared), ValueError)
+        self.grids = g
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
@@ -334,6 +359,18 @@ class VecReferenceModel:
         out = torch.empty_like(self._obs)
         self._check(self._lib.mapf_observe(self._h, C.c_void_p(out.data_ptr()), self._stream()))
         return out
+
+    def assign_new_goal(self, env: int, agent: int) -> np.ndarray:
+        """`_assign_new_goal(agent_idx)` of one env (MA-env:284-304) by itself, on the device: a new goal among the free
+        cells that hold neither an agent nor a goal, chosen with ``rng.integers(k)`` on the env's stream.  Returns the
+        new goal int16 [row, col]; raises RuntimeError when there is no such cell (the reference's error, :296-298)."""
+        goal = np.zeros(2, dtype=np.int16)
+        rc = self._lib.mapf_assign_new_goal(self._h, int(env), int(agent), goal.ctypes.data_as(C.c_void_p), self._stream())
+        if rc == L.MAPF_ERR_NO_RESPAWN:
+            self._lib.mapf_poll_error(self._h, self._stream(), None, None, None)  # (clears the latched record)
+            raise RuntimeError("No valid cell available for lifelong goal reassignment.")
+        self._check(rc)
+        return goal
 
     def step_raw(self, actions_ptr: int, stream_ptr: int, auto_reset: int = 1) -> int:
         """Lowest-overhead launch for benchmarks: raw device pointer in, preallocated outputs."""

@@ -125,7 +125,9 @@ class VecSingleAgentReferenceModel:
     def step_many(self, actions: torch.Tensor, obs_mode: int = 1) -> dict:
         """T fused steps in one launch (mapf_cte_step_many).  actions: int8 [T, B, N].  Returns fresh tensors: obs
         ([B, row] for obs_mode 1, [T, B, row] for 2, None for 0), reward [T, B] float64, terminated / truncated [T, B],
-        info [T, B, 4].  Finished envs are reset inside the launch (their row of that step is the reset observation)."""
+        info [T, B, 4].  Finished envs are reset inside the launch (their row of that step is the reset observation).
+        Call poll_error() afterwards: an invalid action is latched there, and the rows of that env from that step on are
+        zeros, not results."""
         if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
         T, B = int(actions.shape[0]), self.num_envs
@@ -137,15 +139,31 @@ class VecSingleAgentReferenceModel:
             obs = torch.empty((B, self.obs_len), dtype=torch.float32, device=dev)
         elif obs_mode == 2:
             obs = torch.empty((T, B, self.obs_len), dtype=torch.float32, device=dev)
-        out = {"obs": obs, "reward": torch.empty((T, B), dtype=torch.float64, device=dev),
-               "terminated": torch.empty((T, B), dtype=torch.uint8, device=dev),
-               "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev),
-               "info": torch.empty((T, B, 4), dtype=torch.float32, device=dev)}
+        # zero-filled, not empty: the kernel skips the output stores of a step in which an env hit an invalid action
+        # (SA-env:401-403 raises there), so those [t, env] rows would otherwise hold uninitialised memory.  Such an env is
+        # reported by poll_error(), which a caller of step_many must consult (it synchronises, so it is not done here).
+        out = {"obs": obs, "reward": torch.zeros((T, B), dtype=torch.float64, device=dev),
+               "terminated": torch.zeros((T, B), dtype=torch.uint8, device=dev),
+               "truncated": torch.zeros((T, B), dtype=torch.uint8, device=dev),
+               "info": torch.zeros((T, B, 4), dtype=torch.float32, device=dev)}
         self._check(self._lib.mapf_cte_step_many(
             self._h, T, C.c_void_p(actions.data_ptr()), None if obs is None else C.c_void_p(obs.data_ptr()), int(obs_mode),
             C.c_void_p(out["reward"].data_ptr()), C.c_void_p(out["terminated"].data_ptr()),
             C.c_void_p(out["truncated"].data_ptr()), C.c_void_p(out["info"].data_ptr()), self._stream()))
         return out
+
+    def set_step_counts(self, counts) -> None:
+        """Put env b `counts[b]` steps into its episode (staggered episode boundaries for benchmarks and tests)."""
+        c = self.get_state()["counters"]
+        c[:, L.CTR_STEP_COUNT] = np.asarray(counts, dtype=np.int32)
+        s = L.MapfState(counters=c.ctypes.data_as(C.c_void_p))
+        self._check(self._lib.mapf_set_state(self._h, C.byref(s)), ValueError)
+
+    def launch_info(self) -> dict:
+        b, t, l, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
+        return {"blocks": b.value, "threads": 128, "lds_bytes": l.value, "lanes_per_env": p.value, "specialized_kernel": 0,
+                "jit": False, "jit_note": "single-agent env"}
 
     def poll_error(self):
         env, agent, value = C.c_int32(-1), C.c_int32(-1), C.c_int32(0)

@@ -26,6 +26,9 @@ WORKLOADS = {
     # 16 agents, sensor_range 3, no action mask in the observation) on synthetic 32x32 grids, for the secondary numbers
     "ref_training_4096x32x32_n16": (4096, 32, 32, 16, 0.20, {"sensor_range": 3, "include_action_mask_in_obs": False,
                                                               "steps_per_episode": 256}),
+    # the single-agent (CTE) sibling env: full-grid observation, one policy moves all agents
+    "cte_8192x16x16_n4": (8192, 16, 16, 4, 0.20, {"single_agent": True}),
+    "cte_1024x32x32_n8": (1024, 32, 32, 8, 0.20, {"single_agent": True}),
 }
 HEADLINE = "c3_8192x32x32_n8"  # BASELINE.json metric: agent-steps/sec at 8192 envs x 8 agents on 32x32
 
@@ -56,6 +59,10 @@ def workload_config(name: str, env_ids) -> dict:
     return cfg
 
 
+def is_single_agent(name: str) -> bool:
+    return bool(WORKLOADS[name][5].get("single_agent", False))
+
+
 def obs_len(cfg: dict) -> int:
     v = 2 * int(cfg.get("sensor_range", 1)) + 1
     return (v * v + 2 + (1 if cfg.get("include_goal_distance", False) else 0)
@@ -66,3 +73,11 @@ def obs_len(cfg: dict) -> int:
 def algorithmic_bytes_per_env_step(n_agents: int, obs_floats: int, h: int, w: int) -> int:
     """N*(41 + 4L) + H*W + 122 bytes per env-step."""
     return n_agents * (41 + 4 * obs_floats) + h * w + 122
+
+
+def cte_algorithmic_bytes_per_env_step(n_agents: int, h: int, w: int) -> int:
+    """The single-agent env's counterpart of the figure above (SURVEY 8(d) has none for it; stated in DESIGN.md): the
+    observation row written (H*W + 5N floats), the 8-byte hot plane of every agent and the 64-byte env scalars read and
+    written, obstacle rows (8 B per grid row) and the action bytes read, reward (f64), two done flags and four info
+    floats written."""
+    return 4 * (h * w + 5 * n_agents) + 2 * 8 * n_agents + 2 * 64 + 8 * h + n_agents + 8 + 2 + 16

@@ -37,6 +37,8 @@
  *   mapf_observe          <- get_obs / get_action_mask / _flatten_observation called on a static state
  *                                                               MA-env:707-773, :306-328
  *   mapf_obs_len          <- _build_obs_layout                  MA-env:238-265
+ *   mapf_assign_new_goal  <- _assign_new_goal(agent_idx) called by itself (the reference's lifelong tests do,
+ *                            tests/test_reference_model_lifelong.py:132-173)                     MA-env:284-304
  */
 #ifndef MAPF_STEP_H
 #define MAPF_STEP_H
@@ -69,6 +71,11 @@ extern "C" {
                                                one for exactly this configuration at mapf_create (hiprtc, a few seconds;
                                                cached per process).  Falls back to the runtime-config kernels -- with the
                                                reason in mapf_jit_status() -- when hiprtc or the kernel source is not there */
+#define MAPF_FLAG_FORCE_DENSE 0x08000000u   /* engine knob (tests): the 128-register builds of the small-group step kernels
+                                             * whatever the size of the grid (mapf_create picks by grid size otherwise) */
+#define MAPF_FLAG_FORCE_SPARSE 0x04000000u  /* engine knob (tests): never the 128-register builds */
+#define MAPF_FLAG_SAMPLER_WORKGROUPS 0x02000000u /* engine knob (tests): the runtime-config kernels pre-draw placements in
+                                             * sampler workgroups of the step grid instead of slices inside the env workgroups */
 #define MAPF_FLAG_SEQUENTIAL_RESET 0x20000000u /* engine knob (tests): in-kernel resets always take the sequential
                                                  * sampler (otherwise only after a Lemire rejection or when F = 2N) */
 #define MAPF_FLAG_NO_CELL_MAP 0x40000000u   /* engine knob (tests / A-B): never use the LDS cell-map path of wide groups */
@@ -172,8 +179,9 @@ int32_t mapf_obs_len(const mapf_config *cfg);
 
 /* mapf_create also picks the build of the step kernel by the size of its grid: small-group configurations (at most 16
  * lanes per env) exist for two register budgets, and a grid of more than three waves per SIMD gets the 128-register
- * one.  Environment variable MAPF_FORCE_DENSE=0|1 overrides the choice (test knob; results are
- * identical either way). */
+ * one.  MAPF_FLAG_FORCE_DENSE / MAPF_FLAG_FORCE_SPARSE override the choice (test knobs; results are
+ * identical either way).  The library reads no environment variable except MAPF_JIT_CACHE_DIR (and XDG_CACHE_HOME /
+ * HOME behind it) for the on-disk cache of MAPF_FLAG_JIT_SPECIALIZE. */
 int mapf_create(const mapf_config *cfg /* host */, mapf_handle *out);
 int mapf_destroy(mapf_handle h);
 const char *mapf_last_error(mapf_handle h); /* h may be NULL: error of the last failed mapf_create */
@@ -276,6 +284,14 @@ int mapf_cte_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *o
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().
  * obs: device float32 [B][N][L]. */
 int mapf_observe(mapf_handle h, float *obs /* device */, void *stream);
+
+/* one goal respawn of one agent OUTSIDE step(): `_assign_new_goal(agent_idx)` (MA-env:284-304) -- clears the agent's goal,
+ * counts the k free cells (row-major `_free_positions`) that hold no agent and no goal, draws rng.integers(k) from the
+ * env's stream (nothing is drawn when k == 1), stores the r-th such cell as the new goal and returns it in
+ * new_goal (host int16 [2]: row, col).  Runs on `stream` and waits for it.  MAPF_ERR_NO_RESPAWN when k == 0 (the
+ * reference's RuntimeError, :296-298; also latched for mapf_poll_error).  Inside mapf_step the respawns of lifelong
+ * mode run in the step kernel; this entry point is the helper by itself, as the reference's tests call it. */
+int mapf_assign_new_goal(mapf_handle h, int32_t env, int32_t agent, int16_t *new_goal /* host */, void *stream);
 
 /* sums of the per-env episode accumulators over all envs of the handle: host int64 out[MAPF_NUM_EPISODE_ACC];
  * reset != 0 clears them afterwards.  Synchronizes the device.  (Off the hot path; for a multi-GPU job add the

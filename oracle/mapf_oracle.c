@@ -1044,3 +1044,29 @@ void moc_view(moc_env *e, int32_t **positions, int32_t **goals, int32_t **starts
     *positions = e->positions; *goals = e->goals; *starts = e->starts; *reached_once = e->reached_once;
     *step_count = &e->step_count; *blocking_count = &e->episode_blocking_count;
 }
+
+/* Timing helper for bench.py's cpu_baseline leg of the single-agent env: `steps` steps of B envs with the loop the
+ * reference's callers run (obs, r, term, trunc, info = env.step(a); if term or trunc: env.reset(), around SA-env:246-363 /
+ * :222-244), in one call so that no Python sits between the steps.  actions int8 [P][B][N], step t uses row t mod P;
+ * obs_scratch float [moc_obs_len].  Returns the number of episodes finished, or a negative error code. */
+long moc_run(moc_env **envs, int B, const int8_t *actions, int P, int steps, float *obs_scratch) {
+    long episodes = 0;
+    int32_t act[64];
+    for (int t = 0; t < steps; t++) {
+        const int8_t *row = actions + (size_t)(t % P) * B * envs[0]->N;
+        for (int b = 0; b < B; b++) {
+            moc_env *e = envs[b];
+            for (int i = 0; i < e->N && i < 64; i++) act[i] = row[(size_t)b * e->N + i];
+            double r;
+            uint8_t done[2];
+            float info[4];
+            int rc = moc_step(e, act, obs_scratch, &r, done, info);
+            if (rc != MO_OK) return rc;
+            if (done[0] || done[1]) {
+                moc_reset(e, obs_scratch);
+                episodes++;
+            }
+        }
+    }
+    return episodes;
+}

@@ -156,6 +156,8 @@ void moc_set_fixed_starts_goals(moc_env *e, const int32_t *starts, const int32_t
 void moc_generate_starts_goals(moc_env *e);
 void moc_reset(moc_env *e, float *obs);
 int moc_step(moc_env *e, const int32_t *action, float *obs, double *reward, uint8_t *done, float *info);
+/* timing helper (bench.py cpu_baseline of the single-agent env): `steps` steps of B envs with reset-on-done, one call */
+long moc_run(moc_env **envs, int B, const int8_t *actions /* [P][B][N] */, int P, int steps, float *obs_scratch);
 void moc_view(moc_env *e, int32_t **positions, int32_t **goals, int32_t **starts, uint8_t **reached_once,
               int32_t **step_count, double **blocking_count);
 

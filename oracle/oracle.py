@@ -561,3 +561,34 @@ class OracleCteEnv:
         info = np.zeros(4, dtype=np.float32)
         rc = lib().moc_step(self._h, _ptr(a), _ptr(obs), C.byref(rew), _ptr(done), _ptr(info))
         return rc, obs, float(rew.value), bool(done[0]), bool(done[1]), info
+
+
+class OracleCteBatch:
+    """B single-agent envs stepped by one C loop (moc_run): bench.py's cpu_baseline for the single-agent workloads."""
+
+    def __init__(self, grids, env_config: dict, seeds=None):
+        grids = np.ascontiguousarray(grids, dtype=np.uint8)
+        self.B = grids.shape[0]
+        seeds = list(range(self.B)) if seeds is None else list(seeds)
+        self.envs = [OracleCteEnv(grids[b], dict(env_config, seed=int(seeds[b]))) for b in range(self.B)]
+        self.N = self.envs[0].N
+        self._handles = (C.c_void_p * self.B)(*[e._h for e in self.envs])
+        self._scratch = np.zeros(self.envs[0].L, dtype=np.float32)
+        lib().moc_run.restype = C.c_long
+        lib().moc_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+
+    def reset(self):
+        for e in self.envs:
+            e.reset()
+
+    def set_step_counts(self, counts):
+        for e, c in zip(self.envs, counts):
+            e._step[0] = int(c)
+
+    def run(self, actions, steps: int) -> int:
+        a = np.ascontiguousarray(actions, dtype=np.int8)
+        assert a.ndim == 3 and a.shape[1:] == (self.B, self.N)
+        rc = lib().moc_run(self._handles, self.B, _ptr(a), int(a.shape[0]), int(steps), _ptr(self._scratch))
+        if rc < 0:
+            raise ValueError(f"oracle: moc_run failed rc={rc}")
+        return int(rc)

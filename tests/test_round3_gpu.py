@@ -246,21 +246,27 @@ def test_set_grids_keeps_the_visible_stream_of_envs_with_a_pending_placement():
 
 
 @pytest.mark.parametrize("rt_sliced", [True, False])
-def test_failed_run_time_specialisation_falls_back_with_a_background_draw(monkeypatch, rt_sliced):
+def test_failed_run_time_specialisation_falls_back_with_a_background_draw(monkeypatch, rt_sliced, tmp_path):
     """A requested specialisation that does not come about leaves the handle on the runtime-config kernels WITH a
     background draw: the sliced one of full 4 / 8-agent groups (three-wave kernel on a small grid), or -- the knob that
-    keeps such shapes off it -- the sampler workgroups of the two-wave kernel."""
+    keeps such shapes off it -- the sampler workgroups of the two-wave kernel.  The failure is a real one: a copy of the
+    library installed WITHOUT the kernel source next to it (what a stripped deployment looks like)."""
+    import shutil
+
+    from dl_reference_models_amd import _lib as L
     from dl_reference_models_amd.vec_env import VecReferenceModel
 
-    monkeypatch.setenv("MAPF_JIT_FORCE_FAIL", "1")
-    if not rt_sliced:
-        monkeypatch.setenv("MAPF_RT_SLICED", "0")
+    lone = tmp_path / "libmapfstep.so"
+    shutil.copy(L.SO_PATH, lone)
+    monkeypatch.setenv("MAPF_LIB", str(lone))
     B, n = 64, 8
     cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 1, "steps_per_episode": 9, "num_envs": B,
            "grid": synth_grids(B, 10, 10, 0.1, n), "seeds": list(range(B)), "jit_specialize": True}
+    if not rt_sliced:
+        cfg["background_draw"] = "sampler_workgroups"
     env = VecReferenceModel(cfg)
     info = env.launch_info()
-    assert not info["jit"]
+    assert not info["jit"] and "not found next to the library" in info["jit_note"]
     if rt_sliced:
         assert "sliced background draw" in info["jit_note"] and info["threads"] == 192
     else:
@@ -497,10 +503,10 @@ def test_runtime_config_kernels_with_the_sliced_draw_match_the_oracle(shape, den
     import torch
 
     B, H, W, N, sr, spe, extra = shape
-    if dense:
-        monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
     cfg = {"env_name": "synthetic", "num_agents": N, "sensor_range": sr, "include_action_mask_in_obs": True, "steps_per_episode": spe}
     cfg.update(extra)
+    if dense:
+        cfg["register_budget"] = "dense"
     grids = synth_grids(B, H, W, 0.1, N, base_seed=44_000)
     seeds = list(range(300, 300 + B))
     eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)

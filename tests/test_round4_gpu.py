@@ -1,0 +1,243 @@
+"""Round-4 additions, each against the oracle or a reference-recorded fixture:
+  * the hand-checked known answer of the reference's tests/get_obs.py:141-164 through the HIP path (mapf_observe and the
+    facade's get_obs / get_action_mask), not only through the oracle;
+  * `_assign_new_goal(agent_idx)` called by itself (MA-env:284-304; the reference's lifelong tests do,
+    tests/test_reference_model_lifelong.py:132-173): mapf_assign_new_goal vs the oracle's mo_assign_new_goal, goals and
+    generator words, in lifelong mode, in finite mode with a pre-drawn placement pending, and with k = 1 (no draw);
+  * mapf_set_grids fixes the visible streams and the pass bits on the device (no host round trip);
+  * the c5 shape against the oracle at its full batch of 1 024 envs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from trace_util import EngineStepper, OracleStepper, _eq, load_golden, synth_grids
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- tests/get_obs.py:141-164 ------------------------------------------------------------------------------------------
+def test_get_obs_known_answer_through_the_hip_path():
+    ka = load_golden("g5_get_obs_known_answer")
+    sr = int(ka["sensor_range"])
+    v = 2 * sr + 1
+    cfg = {"env_name": "synthetic", "num_agents": 2, "sensor_range": sr, "include_action_mask_in_obs": True,
+           "include_blocking_pressure_in_obs": False, "seed": 0}
+    eng = EngineStepper(ka["grid"][None], cfg, seeds=[0])
+    eng.env.set_state(positions=ka["positions"][None].astype(np.int16), goals=ka["goals"][None].astype(np.int16),
+                      starts=ka["positions"][None].astype(np.int16), clear_episode=True)
+    obs = eng.env.observe().cpu().numpy()[0]  # mapf_observe: [N][L] = local window, goal delta (2), mask (5)
+    for a in (0, 1):
+        _eq(f"local obs of agent {a}", obs[a, : v * v].astype(np.uint8).reshape(v, v), ka[f"expected_obs_agent_{a}"])
+        _eq(f"mask of agent {a}", obs[a, v * v + 2:].astype(np.int8), ka[f"expected_mask_agent_{a}"])
+
+
+def test_get_obs_known_answer_through_the_facade():
+    from dl_reference_models_amd.reference_model_multi_agent import ReferenceModel
+
+    ka = load_golden("g5_get_obs_known_answer")
+    env = ReferenceModel({"env_name": "synthetic", "grid": ka["grid"], "num_agents": 2, "sensor_range": int(ka["sensor_range"]),
+                          "seed": 0})
+    env._positions_arr[:] = ka["positions"]
+    env._starts_arr[:] = ka["positions"]
+    env._goals_arr[:] = ka["goals"]
+    env._rebuild_occupancy_owner()
+    env._rebuild_goal_owner()
+    for a in (0, 1):
+        local = env.get_obs(f"agent_{a}")
+        _eq(f"get_obs(agent_{a})", local, ka[f"expected_obs_agent_{a}"])
+        _eq(f"get_action_mask(agent_{a})", env.get_action_mask(local), ka[f"expected_mask_agent_{a}"])
+
+
+# ---- _assign_new_goal by itself -------------------------------------------------------------------------------------------
+def _assign_both(eng, orc, env, agent):
+    got = eng.env.assign_new_goal(env, agent)
+    rc = orc.batch.envs[env].assign_new_goal(agent)
+    assert rc == 0, rc
+    _eq(f"new goal of env {env} agent {agent}", got, orc.batch.envs[env].goals[agent])
+
+
+@pytest.mark.parametrize("n,H,W,lifelong", [(8, 9, 11, True), (64, 20, 21, True), (5, 7, 7, False)])
+def test_assign_new_goal_matches_the_oracle(n, H, W, lifelong):
+    B = 6
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "steps_per_episode": 40, "lifelong_mapf": lifelong,
+           "include_action_mask_in_obs": True}
+    grids = synth_grids(B, H, W, 0.15, n, base_seed=77_000)
+    seeds = list(range(50, 50 + B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(4)
+    for rnd in range(12):
+        for _ in range(3):  # a few steps in between: positions move, lifelong respawns consume the stream inside step()
+            a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+            ra, rb = eng.step(a), orc.step(a)
+            for k in ("obs", "rewards", "terminated", "truncated", "info_all"):
+                _eq(k, ra[k], rb[k], rnd)
+        for _ in range(4):
+            _assign_both(eng, orc, int(rng.integers(0, B)), int(rng.integers(0, n)))
+        _eq("goals", eng.goals(), orc.goals(), rnd)
+        _eq("rng words", eng.rng_words(), orc.rng_words(), rnd)
+        obs = eng.env.observe().cpu().numpy()  # mapf_observe on the state the respawns left
+        for b in range(B):
+            win, mask = _oracle_windows(orc, b)
+            _eq(f"windows of env {b}", obs[b, :, :25], win, rnd)
+            _eq(f"masks of env {b}", obs[b, :, -5:], mask, rnd)
+
+
+def _oracle_windows(orc, b):
+    """Local windows and masks of env b's agents from its current state through the oracle's own helpers
+    (mo_get_obs / mo_get_action_mask), flattened like the head and tail of an observation row."""
+    e = orc.batch.envs[b]
+    wins = [e.get_obs(a) for a in range(orc.N)]
+    return (np.stack([w.ravel() for w in wins]).astype(np.float32),
+            np.stack([e.get_action_mask(w) for w in wins]).astype(np.float32))
+
+
+def test_assign_new_goal_voids_a_pending_placement_and_the_next_reset_still_matches():
+    """Finite mode: the background draw has already advanced the env's stream for the NEXT reset (slot pending, visible state
+    in vis_rng).  A respawn by itself draws from the VISIBLE state and voids that placement; the following resets must be
+    the oracle's."""
+    B, n = 64, 8
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "steps_per_episode": 30, "include_action_mask_in_obs": True}
+    grids = synth_grids(B, 12, 12, 0.1, n, base_seed=78_000)
+    seeds = list(range(B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(5)
+
+    def steps(k, tag):
+        for t in range(k):
+            a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+            ra, rb = eng.step(a), orc.step(a)
+            for key in ("obs", "rewards", "terminated", "truncated", "info_all"):
+                _eq(key, ra[key], rb[key], f"{tag}{t}")
+
+    steps(14, "a")  # (seven slices: every env has a placement pending by now)
+    slots = np.zeros((B, n), np.uint32)
+    eng.env._lib.mapf_debug_slots(eng.env._h, slots.ctypes.data_as(C.c_void_p), None, None)
+    pending = np.flatnonzero(slots[:, 0] != 0xFFFFFFFF)
+    assert len(pending) > B // 2, "expected pre-drawn placements by step 14"
+    idle = np.flatnonzero(slots[:, 0] == 0xFFFFFFFF)
+    for env in pending[:20].tolist() + idle[:2].tolist():
+        _assign_both(eng, orc, int(env), int(rng.integers(0, n)))
+    _eq("rng words", eng.rng_words(), orc.rng_words())
+    _eq("goals", eng.goals(), orc.goals())
+    steps(40, "b")  # across the episode boundary: every env resets from the stream the respawn left
+    _eq("rng words after the resets", eng.rng_words(), orc.rng_words())
+
+
+def test_assign_new_goal_with_one_candidate_draws_nothing():
+    """1 x 4 corridor, 2 agents, F = 2N: with the other agent's goal on a free cell the asking agent has exactly one
+    candidate -- its own old goal -- and rng.integers(1) consumes nothing (NumPy returns 0 without a draw).  k = 0, the
+    reference's RuntimeError (MA-env:296-298), cannot be reached from a valid state: k >= F - N - (N - 1) >= 1."""
+    grid = np.zeros((1, 1, 4), np.uint8)
+    cfg = {"env_name": "synthetic", "num_agents": 2, "sensor_range": 1, "lifelong_mapf": True}
+    eng, orc = EngineStepper(grid, cfg, seeds=[3]), OracleStepper(grid, cfg, seeds=[3])
+    pos = np.array([[[0, 0], [0, 1]]], np.int16)
+    goals = np.array([[[0, 2], [0, 3]]], np.int16)
+    eng.set_state(pos, goals)
+    orc.set_state(pos, goals)
+    before = eng.rng_words().copy()
+    _assign_both(eng, orc, 0, 0)  # candidates: cell 2 only (0, 1 occupied, 3 is agent 1's goal) -> k = 1
+    assert eng.goals()[0, 0].tolist() == [0, 2]
+    _eq("rng words untouched by k = 1", eng.rng_words(), before)
+    _eq("rng words", eng.rng_words(), orc.rng_words())
+    # F = 6 = 2N with three agents: agent 0 stands on its own goal, the others' goals are free cells: one cell is left
+    grid3 = np.zeros((1, 1, 6), np.uint8)
+    cfg3 = dict(cfg, num_agents=3)
+    eng3, orc3 = EngineStepper(grid3, cfg3, seeds=[4]), OracleStepper(grid3, cfg3, seeds=[4])
+    pos3 = np.array([[[0, 0], [0, 1], [0, 2]]], np.int16)
+    goals3 = np.array([[[0, 0], [0, 3], [0, 4]]], np.int16)
+    eng3.set_state(pos3, goals3)
+    orc3.set_state(pos3, goals3)
+    _assign_both(eng3, orc3, 0, 0)
+    assert eng3.goals()[0, 0].tolist() == [0, 5]
+    _eq("rng words", eng3.rng_words(), orc3.rng_words())
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng3.env.assign_new_goal(0, 3)
+
+
+def test_facade_assign_new_goal_matches_the_oracle():
+    """The drop-in's `_assign_new_goal(agent_idx)` (the reference's lifelong tests call it, :132-173)."""
+    from dl_reference_models_amd.reference_model_multi_agent import ReferenceModel
+    import oracle as orc_mod
+
+    grid = synth_grids(1, 10, 12, 0.2, 4, base_seed=91_000)[0]
+    cfg = {"env_name": "synthetic", "grid": grid, "num_agents": 4, "sensor_range": 2, "lifelong_mapf": True, "seed": 21}
+    env = ReferenceModel(cfg)
+    ref = orc_mod.OracleEnv(grid, cfg)
+    obs, _ = env.reset()
+    ref.reset()
+    _eq("positions after reset", env._positions_arr, ref.positions)
+    for k in range(10):
+        a = k % 4
+        new_goal = env._assign_new_goal(a)
+        assert ref.assign_new_goal(a) == 0
+        _eq(f"returned goal {k}", np.asarray(new_goal), ref.goals[a])
+        _eq(f"_goals_arr {k}", env._goals_arr, ref.goals)
+        assert new_goal.dtype == env._coord_dtype
+    _eq("rng words", env._engine.get_state()["rng_words"][0], ref.rng_words())
+    # and the next step still matches (the goal owner map of the kernel is derived from the goals it reads)
+    acts = {f"agent_{i}": int(i % 5) for i in range(4)}
+    o, r, *_ = env.step(acts)
+    rc, o2, r2, *_ = ref.step(np.array([acts[f"agent_{i}"] for i in range(4)], np.int32))
+    assert rc == 0
+    for i in range(4):
+        _eq(f"obs agent {i}", o[f"agent_{i}"], o2[i])
+
+
+# ---- mapf_set_grids: device-side fix-ups ------------------------------------------------------------------------------
+def test_set_grids_recomputes_pass_bits_on_the_device():
+    """After new grids the agents' pass bits (which neighbours the grid lets them step on) come from the new rows: a move
+    into a cell that has become free must succeed, a move into a new obstacle must fail -- engine vs oracle built on the new
+    grids with the same state."""
+    B, n, H, W = 9, 8, 10, 10
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "steps_per_episode": 50, "include_action_mask_in_obs": True}
+    g1 = synth_grids(B, H, W, 0.3, n, base_seed=81_000)
+    eng = EngineStepper(g1, cfg, seeds=list(range(B)))
+    eng.reset()
+    st = eng.env.get_state()
+    # new grids: obstacles reshuffled except under agents and goals (so the state stays valid)
+    g2 = synth_grids(B, H, W, 0.3, n, base_seed=82_000)
+    for b in range(B):
+        for cell in np.concatenate([st["positions"][b], st["goals"][b]]):
+            g2[b, cell[0], cell[1]] = 0
+    eng.env.set_grids(g2)
+    orc = OracleStepper(g2, cfg, rng_words=eng.rng_words())
+    orc.set_state(st["positions"], st["goals"], rng_words=eng.rng_words())
+    eng.set_state(st["positions"], st["goals"], rng_words=eng.rng_words())  # (clears episode bookkeeping on both sides)
+    rng = np.random.default_rng(8)
+    for t in range(30):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all"):
+            _eq(k, ra[k], rb[k], t)
+    _eq("positions", eng.positions(), orc.positions())
+
+
+# ---- c5 at its full batch -----------------------------------------------------------------------------------------------
+def test_engine_vs_oracle_c5_full_batch():
+    """BASELINE config 5 at B = 1 024 (it was compared at B = 256 only): 64 x 64, 64 agents, lifelong."""
+    from dl_reference_models_amd import workloads as wl
+
+    name = "c5_1024x64x64_n64_lifelong"
+    B = wl.WORKLOADS[name][0]
+    ids = list(range(B))
+    cfg = wl.workload_config(name, ids)
+    grids = cfg.pop("grid")
+    seeds = cfg.pop("seeds")
+    cfg.pop("num_envs")
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    assert eng.env.launch_info()["specialized_kernel"] == 3
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(999)
+    for t in range(12):
+        a = rng.integers(0, 5, size=(B, 64)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            _eq(k, ra[k], rb[k], t)
+    _eq("goals", eng.goals(), orc.goals())
+    _eq("rng words", eng.rng_words(), orc.rng_words())

@@ -20,18 +20,17 @@ pytestmark = pytest.mark.gpu
 def test_short_soak_matches_oracle(master, cases, only_n, dense, check, monkeypatch):
     """dense = "1": the 128-register two-wave build of the specialised step kernels (k_step's WPS = 4: no speculative
     slice loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per
-    SIMD (MAPF_FORCE_DENSE is read by mapf_create); without it the small-group shapes run the three-wave kernel.
+    SIMD (`register_budget` engine knob = MAPF_FLAG_FORCE_DENSE); without it the small-group shapes run the three-wave kernel.
     check: the same soak on the CHECKING build (-DMAPF_CHECK: every data-dependent LDS scatter / gather index of the
     draw, the inline reset and the staging rows is range-checked against its lane group's region and latches
     MAPF_ERR_INTERNAL): the build that would have reported round 2's draw_shuffle16 bug at the store instead of 200 cases
     later as a wrong goal cell."""
     from soak_specialized import run_soak
-    if dense is not None:
-        monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
     if check:
         monkeypatch.setenv("MAPF_CHECK_BUILD", "1")
     lines = []
-    err = run_soak(master, cases, only_n=only_n, log=lines.append, poll_errors=check)
+    err = run_soak(master, cases, only_n=only_n, log=lines.append, poll_errors=check,
+                   knobs={"register_budget": "dense"} if dense else None)
     assert err is None, err + "\n" + "\n".join(lines[-8:])
 
 
@@ -63,13 +62,14 @@ def test_checking_build_latches_an_index_outside_its_region(monkeypatch):
 def test_short_soak_of_the_runtime_config_kernels(master, cases, dense, sampler, only_n, monkeypatch):
     """The same soak with the runtime-config kernels forced onto the prebuilt shapes (SOAK_GENERIC): full groups of 4 / 8
     agents draw in slices and run the three-wave kernel (KRuntimeSliced), its two-wave 128-register build (dense), or --
-    MAPF_RT_SLICED=0 -- the sampler workgroups they used before round 3."""
+    `background_draw: "sampler_workgroups"` -- the sampler workgroups they used before round 3."""
     from soak_specialized import run_soak
     monkeypatch.setenv("SOAK_GENERIC", "1")
+    knobs = {}
     if dense is not None:
-        monkeypatch.setenv("MAPF_FORCE_DENSE", dense)
+        knobs["register_budget"] = "dense"
     if sampler:
-        monkeypatch.setenv("MAPF_RT_SLICED", "0")
+        knobs["background_draw"] = "sampler_workgroups"
     lines = []
-    err = run_soak(master, cases, only_n=only_n, log=lines.append)
+    err = run_soak(master, cases, only_n=only_n, log=lines.append, knobs=knobs)
     assert err is None, err + "\n" + "\n".join(lines[-8:])

@@ -7,7 +7,7 @@ also end by success at arbitrary steps), with and without the terminal observati
 positions, goals and generator words every few steps.  tests/test_soak_gpu.py runs a short one (run_soak below); the
 long ones are recorded in DESIGN.md section 2.
 Usage: python tools/soak_specialized.py [master_seed] [cases]
-Environment: SOAK_GENERIC=1 (the runtime-config kernels on the same shapes), SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
+Environment: SOAK_GENERIC=1 (the runtime-config kernels on the same shapes), SOAK_DENSE=1 (the 128-register builds), SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
 reset, the A/B), SOAK_ONLY=<case> (run one case of the sequence), SOAK_WATCH=<case>:<env> (print that env's placement slot
 and staging buffer before every step).  Cases are NOT independent on the GPU side: what a kernel finds in LDS depends on
 the launches before it, so a failure is reported with its case number in the sequence."""
@@ -19,8 +19,9 @@ from trace_util import EngineStepper, OracleStepper, _eq, synth_grids
 
 
 def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, only=-1, watch=None, log=print,
-             poll_errors=False):
-    """Returns None when every case matched, else the failure text."""
+             poll_errors=False, knobs=None):
+    """Returns None when every case matched, else the failure text.  knobs: engine knobs for every handle (e.g.
+    {"register_budget": "dense"}, {"background_draw": "sampler_workgroups"})."""
     rng = np.random.default_rng(master)
     t0 = time.time()
     for case in range(cases):
@@ -51,8 +52,11 @@ def run_soak(master=2026, cases=200, only_n=None, final=None, sequential=False, 
             orc.reset()
         else:
             kw = {"force_sequential_reset": True} if sequential else {}
+            kw.update(knobs or {})
+            if os.environ.get("SOAK_DENSE"):
+                kw["register_budget"] = "dense"
             if os.environ.get("SOAK_GENERIC"):  # the same shapes on the runtime-config kernels (full groups of 4 / 8 agents:
-                kw["force_generic_kernel"] = True  # sliced draw + three-wave kernel since round 3; MAPF_RT_SLICED=0: sampler workgroups)
+                kw["force_generic_kernel"] = True  # sliced draw + three-wave kernel since round 3; background_draw knob: sampler workgroups)
             eng = EngineStepper(grids, cfg, seeds=seeds, want_final_obs=want_final, **kw)
             assert eng.env.launch_info()["specialized_kernel"] in ((0,) if os.environ.get("SOAK_GENERIC") else (1, 2, 4, 5, 6)), eng.env.launch_info()
             _eq("reset obs", eng.reset(), orc.reset())
