@@ -59,6 +59,8 @@ struct LaunchPlan {
     int many_dense;      // k_step_many: idem (more than two)
     int three_wave;      // k_step3
     int rt_sliced;       // runtime-config kernels with the sliced background draw (KRuntimeSliced)
+    int wide3;           // k_stepw: the three-wave kernel of 64-lane groups (one env per workgroup, bit rows in LDS)
+    int wide_lds_bytes;  // its dynamic LDS
 };
 
 enum { KIND_RESET = 0, KIND_STEP = 1, KIND_OBSERVE = 2 };

@@ -410,6 +410,8 @@ struct WMask<32> {
     __device__ __forceinline__ uint32_t nib(int t0) const { return (lo >> t0) & 15u; }
     __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
+    __device__ __forceinline__ bool any() const { return lo != 0; }
+    __device__ __forceinline__ int first() const { return (int)__builtin_ctz(lo); }  // (any() must hold)
 };
 template <>
 struct WMask<64> {
@@ -422,6 +424,8 @@ struct WMask<64> {
     __device__ __forceinline__ uint32_t nib(int t0) const { return (uint32_t)(lo >> t0) & 15u; }
     __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
+    __device__ __forceinline__ bool any() const { return lo != 0; }
+    __device__ __forceinline__ int first() const { return (int)__builtin_ctzll(lo); }
 };
 template <>
 struct WMask<128> {
@@ -449,6 +453,8 @@ struct WMask<128> {
     }
     __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo, hi | o.hi}; }
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo, hi & ~o.hi}; }
+    __device__ __forceinline__ bool any() const { return (lo | hi) != 0; }
+    __device__ __forceinline__ int first() const { return lo ? (int)__builtin_ctzll(lo) : 64 + (int)__builtin_ctzll(hi); }
 };
 
 // V bits of an obstacle row starting at column c0; outside the grid = 1.
@@ -3955,6 +3961,884 @@ __global__ __launch_bounds__(many_threads(LPE), (WPS ? WPS : 1)) void k_step_man
             }
         }
     }
+}
+
+// ================================================================================================
+// Wide three-wave step kernel (round 4): ONE env per workgroup, 33 .. 64 agents (64 lanes per env, lane a = agent a).
+//
+// What round 3's profile of the c5 shape (1 024 envs x 64x64 x 64 agents, lifelong; k_step with the LDS cell map) said:
+// 596 vector instructions per wave but 15.9 k cycles of wave lifetime, two thirds of them in wait states -- nothing is
+// short of issue slots, each wave is one long chain of dependent LDS round trips: 21.9 KB of cell map cleared per env
+// and launch (four workgroups of a CU share one LDS pipe), B1 only after move + goal logic + map fill (5.2 k cycles after
+// the state is in registers), then 25 map reads and their decode per observation window (4.0 k cycles to the staged
+// row) beside 12 map reads + lock detector + info + stores in the state wave (6.1 k).
+//
+// Here an env's step is dealt to three waves that all start from their own loads (as k_step3 does for small groups), and
+// the word-per-cell map is replaced by BIT ROWS (one 64-bit word per grid row: free cells, occupancy before / after
+// the move, cells a successful mover left or entered, goals, intents) plus two byte maps that name the agent on a cell
+// and are only read where a bit row says there is one -- so nothing but ~5 KB of bit rows is cleared per launch, a
+// V x V window is V reads per bit row and a funnel shift each, and index lookups are left for the few cells whose
+// occupancy depends on the observer's turn (MA-env:528: agents <= i at their new cell, agents > i at their old one) and
+// for the few neighbours of the lock detector:
+//   wave 0 (state)  hot plane + actions -> move phase (pass bits: no obstacle rows needed; occupant of the target and
+//                   contention through the bit rows) -> lifelong respawn (MA-env:284-304) -> publish, B1 -> rewards,
+//                   per-agent info, done flags, hot plane; the inline draw of an env that ends its episode;
+//   wave 1 (obs)    obstacle rows -> free-cell bit rows, goal-delta quotient table; after B1 the windows, the flat
+//                   rows (MA-env:306-328) and the observation stream; reset observation of a re-placed env;
+//   wave 2 (aux)    history planes + counters; after B1 lock flags, neighbour sets from the bit rows, lock detector
+//                   (MA-env:374-438), info (:627-656), counters, history planes, episode statistics.
+// Every wave decides for itself how the step ends (wide_decide: same inputs, same answer).  Idle lanes (N < 64), an
+// invalid action (MA-env:502-506: agents before it are processed, nothing after the loop) and a masked-out env are
+// handled in place: the kernel has no fallback path.
+// ================================================================================================
+typedef const __attribute__((address_space(1))) uint16_t global_u16;
+__device__ __forceinline__ global_u16 *as_global(const uint16_t *q) { return (global_u16 *)q; }
+constexpr int kWideBitmaps = 10;       // occO occN mov goalb intent wantb contb occR goalR (cleared at entry) + freeb
+constexpr int kWideCleared = 9;
+constexpr int kWideOwnBytes = 64 * 64;  // byte maps are indexed row * 64 + col
+__host__ __device__ constexpr int wide_rows(int H) { return H + 2 * kRowPad; }
+__host__ __device__ constexpr int wide_lds_bytes(int H, int NL, int scratch_i16) {
+    return kWideBitmaps * wide_rows(H) * 8 + 16 /* alignment slack */ + 3 * kWideOwnBytes + 64 * 16 /* tab */ +
+           64 /* ctl */ + 1024 /* gd_lut */ + 128 /* xinfo */ + ((NL * 4 + 15) & ~15) + ((scratch_i16 * 2 + 15) & ~15);
+}
+struct WideLds {
+    uint64_t *occO, *occN, *mov, *goalb, *intent, *wantb, *contb, *occR, *goalR, *freeb;  // row r at index r + kRowPad
+    uint8_t *ownO, *ownN;  // agent index on a cell before / after the move; valid where occO / occN has the bit
+    uint4 *tab;            // per agent: x old | new << 16, y goal (after a respawn) | arrived << 16, z reset placement
+    int8_t *dmap;          // per CELL: goal-distance delta (livelock window) of the agent standing there after the move (the aux
+                           // wave's, for its neighbour sums: read together with ownN, valid where occN has the bit)
+    uint32_t *ctl;         // wave-uniform words of the state wave: [0] 1 = some goal was respawned in this step
+    float *gd_lut;
+    unsigned char *xinfo;
+    float *stage;
+    int16_t *scratch;
+};
+__device__ __forceinline__ WideLds carve_wide(unsigned char *raw, int H, int NL) {
+    WideLds l;
+    const int rs = wide_rows(H);
+    uint64_t *b = reinterpret_cast<uint64_t *>(raw);
+    l.occO = b; l.occN = b + rs; l.mov = b + 2 * rs; l.goalb = b + 3 * rs; l.intent = b + 4 * rs; l.wantb = b + 5 * rs;
+    l.contb = b + 6 * rs; l.occR = b + 7 * rs; l.goalR = b + 8 * rs; l.freeb = b + 9 * rs;
+    unsigned char *q = raw + ((kWideBitmaps * rs * 8 + 15) & ~15);
+    l.ownO = q; q += kWideOwnBytes;
+    l.ownN = q; q += kWideOwnBytes;
+    l.tab = reinterpret_cast<uint4 *>(q); q += 64 * 16;
+    l.dmap = reinterpret_cast<int8_t *>(q); q += kWideOwnBytes;
+    l.ctl = reinterpret_cast<uint32_t *>(q); q += 64;
+    l.gd_lut = reinterpret_cast<float *>(q); q += 1024;
+    l.xinfo = q; q += 128;
+    l.stage = reinterpret_cast<float *>(q); q += (NL * 4 + 15) & ~15;
+    l.scratch = reinterpret_cast<int16_t *>(q);
+    return l;
+}
+__device__ __forceinline__ int wide_cell(uint32_t cell) { return (int)((cell >> 8) * 64u + (cell & 255u)); }
+__device__ __forceinline__ uint64_t wide_bit(uint32_t cell) { return 1ull << (cell & 63u); }
+__device__ __forceinline__ int wide_row(uint32_t cell) { return (int)(cell >> 8) + kRowPad; }
+// pass bits (mapf_kernels.inl: agent_pass_bits) of a cell from the free-cell bit rows: bit 0 up, 1 right, 2 down, 3 left
+__device__ __forceinline__ uint32_t wide_pass_bits(const uint64_t *freeb, uint32_t cell) {
+    const int r = (int)(cell >> 8) + kRowPad, c = (int)(cell & 255u);
+    const uint64_t up = freeb[r - 1], mid = freeb[r], dn = freeb[r + 1];
+    const uint32_t f_up = (uint32_t)(up >> (c & 63)) & 1u, f_dn = (uint32_t)(dn >> (c & 63)) & 1u;
+    const uint32_t f_rt = c + 1 < 64 ? ((uint32_t)(mid >> ((c + 1) & 63)) & 1u) : 0u;
+    const uint32_t f_lf = c > 0 ? ((uint32_t)(mid >> ((c - 1) & 63)) & 1u) : 0u;
+    return f_up | (f_rt << 1) | (f_dn << 2) | (f_lf << 3);
+}
+// V bits of a bit row starting at column c0 (which may be negative or run past column 63: zeros there)
+__device__ __forceinline__ uint32_t wide_window(uint64_t row, int c0, int V) {
+    const uint32_t right = (uint32_t)(row >> (c0 & 63));
+    const uint32_t left = (uint32_t)row << ((-c0) & 31);
+    return ((c0 >= 0) ? right : left) & ((1u << V) - 1u);
+}
+
+// How the step ends for the env (MA-env:668-690 + auto-reset), identically in all three waves: from the agents' new
+// cells and goals (published before B1), the step counter and the placement slot.
+struct WideEnd {
+    int term, trunc;
+    bool done, do_reset, fast_reset, slow_reset, subst;
+    int sel;  // which tensor the step's observation goes to: 0 io.obs, 1 io.final_obs, 2 nowhere
+};
+template <class K>
+__device__ __forceinline__ WideEnd wide_decide(const Params &p, const Io &io, int N, bool on_goal, bool is_agent, bool errored,
+                                               int step_count, uint32_t nsg) {
+    const uint32_t flags = K::flags(p);
+    const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0, deterministic = (flags & MAPF_FLAG_DETERMINISTIC) != 0;
+    WideEnd d;
+    d.term = d.trunc = 0;
+    if (!lifelong && __popcll(__ballot(on_goal)) == N) {
+        d.term = 1;
+    } else if (step_count >= io.steps_per_episode) {
+        d.term = 1;
+        d.trunc = 1;
+    }
+    d.done = !errored && (d.term | d.trunc) != 0;
+    d.do_reset = d.done && io.auto_reset;
+    d.fast_reset = d.slow_reset = d.subst = false;
+    d.sel = errored ? 2 : (io.obs ? 0 : 2);
+    if (__builtin_expect(d.do_reset, 0)) {
+        bool slot_ok = deterministic;
+        if (!deterministic && !lifelong) slot_ok = __ballot(is_agent && !slot_word_valid(nsg)) == 0;
+        d.fast_reset = slot_ok;
+        d.slow_reset = !slot_ok;
+        d.subst = d.fast_reset && io.final_obs == nullptr;
+        d.sel = io.final_obs ? 1 : ((d.subst && io.obs) ? 0 : 2);
+    }
+    return d;
+}
+
+// ---- the observation of one agent from the bit rows -----------------------------------------------------------------------
+// occ / goals: the bit rows to read occupancy and goals from (the step's, or the reset placement's); final_state: everybody
+// at the cell `occ` shows (reset, or after a lifelong respawn MA-env:565-575), else the staggered view of MA-env:528.
+template <class K, int MW>
+__device__ __forceinline__ void wide_observe(const Params &p, const Io &io, const WideLds &l, const uint64_t *occ,
+                                             const uint64_t *goals, float *srow, bool is_agent, int a, uint32_t cur,
+                                             uint32_t goal, bool final_state, bool pressure, const int env0 = 0) {
+    constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
+    constexpr int LPE = 64;
+    (void)env0; (void)LPE;
+    const int V = K::V(p), sr = K::sr(p);
+    const int myr = is_agent ? (int)(cur >> 8) : 0, myc = is_agent ? (int)(cur & 255u) : 0;
+    const int r0 = myr - sr, c0 = myc - sr;
+    uint64_t rf[MAXV], ro[MAXV], rg[MAXV], rm[MAXV], rb[MAXV];
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {  // all reads of the window issue back to back: one LDS round trip
+        const int ri = r0 + d + kRowPad;
+        rf[d] = (d < V) ? l.freeb[ri] : 0ull;
+        ro[d] = (d < V) ? occ[ri] : 0ull;
+        rg[d] = (d < V) ? goals[ri] : 0ull;
+        rm[d] = (d < V && !final_state) ? l.mov[ri] : 0ull;
+        rb[d] = (d < V && !final_state) ? l.occO[ri] : 0ull;
+    }
+#ifdef MAPF_STAMPS
+    asm volatile("" ::"v"(rf[0]), "v"(ro[V - 1]), "v"(rg[V - 1]));
+#endif
+    MAPF_STAMP_W1(25);  // (sub-stamp: window rows in registers)
+    WMask<MW> obst, agm, gls, pend, was;
+    obst.clear(); agm.clear(); gls.clear(); pend.clear(); was.clear();
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {
+        if (d < V) {
+            const uint32_t vm = (1u << V) - 1u;
+            obst.or_row(~wide_window(rf[d], c0, V) & vm, d * V);
+            agm.or_row(wide_window(ro[d], c0, V), d * V);
+            gls.or_row(wide_window(rg[d], c0, V), d * V);
+            if (!final_state) {
+                pend.or_row(wide_window(rm[d], c0, V), d * V);
+                was.or_row(wide_window(rb[d], c0, V), d * V);
+            }
+        }
+    }
+    MAPF_STAMP_W1(26);  // (sub-stamp: window masks built)
+    if (!final_state) {
+        // A window cell in `mov` -- a successful mover left it and / or entered it -- is occupied for observer i iff the
+        // agent that stood there has not had its turn (i < l) or the one that entered has (i >= e): MA-env:528 sits inside
+        // the move loop.  One cell per lane and round; a lane's window holds a handful at most (all windows of a 64-agent
+        // env: ~80 such cells on 4 096).
+        const WMask<MW> isn = agm;         // occupied after the move
+        agm = agm.andnot(pend);            // the cells nobody moved on: occupied whoever looks
+        while (__any(pend.any())) {
+            // up to four cells per lane and round: their eight index reads share one LDS round trip
+            int b[4], lo[4], en[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                on[k] = pend.any();
+                b[k] = on[k] ? pend.first() : 0;
+                if (on[k]) pend.clear_bit(b[k]);
+                const int d = b[k] / V, e = b[k] - d * V;
+                const int ci = on[k] ? (r0 + d) * 64 + c0 + e : 0;  // (inside the grid: mov only has bits there)
+                lo[k] = (int)l.ownO[ci];
+                en[k] = (int)l.ownN[ci];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool occupied = (was.get(b[k]) && a < lo[k]) || (isn.get(b[k]) && a >= en[k]);
+                agm.set_if(on[k] && occupied, b[k]);
+            }
+        }
+    }
+    MAPF_STAMP_W1(27);  // (sub-stamp: turn-dependent cells resolved)
+    if (!is_agent) return;
+    agm.clear_bit(sr * V + sr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
+    WMask<MW> own;
+    own.clear();
+    window_set<MW>(own, goal, r0, c0, V);
+    const int gdr = (int)((goal >> 8) & 255u) - myr, gdc = (int)(goal & 255u) - myc;
+    emit_obs_row<K, MW, MAXV>(p, srow, obst, agm, gls, own, l.gd_lut[gdr + 63], l.gd_lut[128 + gdc + 63], pressure);
+}
+
+// one contiguous write-through stream of the env's N * L floats
+template <class K>
+__device__ __forceinline__ void wide_flush(const Params &p, const WideLds &l, float *dst_tensor, int env, int lane) {
+    const int NL = K::N(p) * K::L(p);
+    float *dst = dst_tensor + (size_t)env * NL;
+    if ((NL & 3) == 0) {
+        const ObsSink sink = make_obs_sink(dst, (unsigned)NL * 4u);
+        const float4 *s4 = reinterpret_cast<const float4 *>(l.stage);
+        const int n4 = NL >> 2;
+        if (K::kFixed) {
+            const int full = n4 >> 6;
+#pragma unroll
+            for (int r = 0; r < full; r++) store_obs4(sink, (unsigned)(r * 64 + lane) * 16u, s4[r * 64 + lane]);
+            if ((full << 6) + lane < n4) store_obs4(sink, (unsigned)((full << 6) + lane) * 16u, s4[(full << 6) + lane]);
+        } else {
+            for (int k = lane; k < n4; k += 64) store_obs4(sink, (unsigned)k * 16u, s4[k]);
+        }
+    } else {
+        for (int k = lane; k < NL; k += 64) dst[k] = l.stage[k];
+    }
+}
+
+template <class K, int MW>
+__global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp, MAPF_IO_HEAD_PARAMS, const IoTail tail) {
+    constexpr int LPE = 64;
+    MAPF_STAMP_ENTRY();
+    const Params &p = *pp;
+    const Io io = MAPF_IO_JOIN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, a = lane;
+    const int N = K::N(p), H = io.H, W = io.W;
+    const uint32_t flags = K::flags(p);
+    const bool lifelong = (flags & MAPF_FLAG_LIFELONG) != 0, deterministic = (flags & MAPF_FLAG_DETERMINISTIC) != 0;
+    const bool lock_on = (flags & MAPF_FLAG_LOCK_METRICS) != 0;
+    const int lead = K::kSamplerFront ? sampler_blocks_for(io.B, 3) : 0;
+    const int env = (int)blockIdx.x - lead;
+    const int env0 = env;  // (stamp macros: one workgroup per env, stamp rows are indexed by it)
+    (void)env0;
+    if (__builtin_expect(env < 0 || env >= io.B, 0)) {  // a sampler workgroup (finite episodes with sampled placements)
+        const int si = K::kSamplerFront ? (int)blockIdx.x : (int)blockIdx.x - io.B;
+        sampler_wave<K, LPE>(p, io, lds_raw + wv * sampler_lds_bytes_per_wave(1, p.scratch_i16), si * 3 + wv, lane, io.B + si);
+        return;
+    }
+    // mapf_step_masked: nothing of a masked-out env is touched (all three waves leave before any barrier)
+    if (__builtin_expect(io.env_mask != nullptr, 0)) {
+        if (io.env_mask[env] == 0) return;
+    }
+    const bool is_agent = a < N;
+    const size_t idx0 = (size_t)env * N;
+    const size_t idx = idx0 + min(a, N - 1);
+    __builtin_amdgcn_s_setprio(2);
+
+    // every wave reads the hot plane and the actions itself (512 + 64 bytes): no wave waits for another one's loads
+    const uint2 hot = io.agents[idx];
+    int act = (int)io.actions[idx];
+
+    if (wv == 1) {
+        // =================================== observation wave ===================================
+        const uint64_t *src = io.grid_rows + (size_t)env * H;
+        const uint64_t grow = src[min(a, H - 1)];
+        const uint32_t nsg = (lifelong || deterministic) ? kSlotInvalid : slots_of(io.scal, io.B)[idx];
+        const int step1 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
+        __builtin_amdgcn_sched_barrier(0);
+        warm_scalar_cache(pp, tail);
+        const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
+        {   // goal-delta quotients (MA-env:330-335) of every delta a <= 64 x 64 grid has, correctly rounded divide, computed
+            // under the latency of the loads above
+            const bool norm = (flags & MAPF_FLAG_NORMALIZE_GOAL_DELTA) != 0;
+#pragma unroll
+            for (int k = lane; k < 128; k += 64) {
+                l.gd_lut[k] = goal_delta(k - 63, io.den_r, norm);
+                l.gd_lut[128 + k] = goal_delta(k - 63, io.den_c, norm);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {   // free-cell bit rows: bit c of row r = cell (r, c) is inside the grid and no obstacle; pad rows are zero
+            const uint64_t colmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+            if (a < H) l.freeb[kRowPad + a] = ~(grow >> io.col_pad) & colmask;
+            if (a < 2 * kRowPad) l.freeb[a < kRowPad ? a : H + a] = 0ull;
+        }
+        MAPF_STAMP_W1(10);
+        const bool bad = is_agent && (act < 0 || act > 4);
+        const uint64_t badm = __ballot(bad);
+        const bool errored = badm != 0;
+        const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+        const uint32_t goal0 = hot.x >> 16;
+        const bool pressure_prev = ((hot.y >> 16) & kFlagPressure) != 0;
+        (void)goal0;
+        // (everything this wave loaded is in registers before the barrier: behind it the other waves store the new state)
+        asm volatile("" ::"v"(hot.x), "v"(hot.y), "v"(nsg), "s"(step1));
+        wg_sync();  // B1
+        __builtin_amdgcn_s_setprio(3);
+        MAPF_STAMP_W1(11);
+        const bool want_obs = io.obs != nullptr || io.final_obs != nullptr;
+        const uint4 ent = l.tab[a];
+        const uint32_t cur = ent.x >> 16, goal = ent.y & 0xFFFFu;
+        const bool reassigned = l.ctl[0] != 0u;
+        const bool on_goal = is_agent && a < n_live && cur == (hot.x >> 16);  // (against the goal BEFORE a respawn, like step_body)
+        const WideEnd dec = wide_decide<K>(p, io, N, on_goal, is_agent, errored, step1 + 1, nsg);
+        float *srow = l.stage + (size_t)min(a, N - 1) * K::L(p);
+        // the placement a fast reset installs (deterministic: reset() keeps the goals, MA-env:452-455)
+        const uint32_t rs = deterministic ? ((hot.y & 0xFFFFu) | (goal << 16)) : nsg;
+        if (want_obs && dec.sel != 2 && !dec.subst) {
+            wide_observe<K, MW>(p, io, l, l.occN, l.goalb, srow, is_agent, a, cur, goal, reassigned, pressure_prev, env0);
+            wave_lds_sync();
+            MAPF_STAMP_W1(12);
+            wide_flush<K>(p, l, dec.sel == 0 ? io.obs : io.final_obs, env, lane);
+            MAPF_STAMP_W1(13);
+        }
+        if (__builtin_expect(dec.do_reset, 0)) {
+            if (dec.slow_reset) wg_sync();  // B2: the state wave has drawn the placement (tab[].z, occR / goalR)
+            if (io.obs) {
+                uint32_t place = rs;
+                if (dec.fast_reset) {  // the placement is known here: its bit rows are built by this wave
+                    if (is_agent) {
+                        atomicOr(reinterpret_cast<unsigned long long *>(&l.occR[wide_row(rs & 0xFFFFu)]), wide_bit(rs & 0xFFFFu));
+                        atomicOr(reinterpret_cast<unsigned long long *>(&l.goalR[wide_row(rs >> 16)]), wide_bit(rs >> 16));
+                    }
+                } else {
+                    place = l.tab[a].z;
+                }
+                wave_lds_sync();  // (also: the staging row of the first pass has been read by its flush)
+                wide_observe<K, MW>(p, io, l, l.occR, l.goalR, srow, is_agent, a, place & 0xFFFFu, place >> 16, true, false);
+                wave_lds_sync();
+                wide_flush<K>(p, l, io.obs, env, lane);
+            }
+        }
+#ifdef MAPF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MAPF_STAMP_W1(14);
+#endif
+        return;
+    }
+
+    if (wv == 2) {
+        // =================================== aux wave ===================================
+        LaneRaw raw;
+        raw.h = hot;
+        lane_issue_hist(io.agents, io.bn8, idx, raw);
+        int sc[12];
+        load_scal(io.scal, env, sc);
+        const uint32_t nsg = (lifelong || deterministic) ? kSlotInvalid : slots_of(io.scal, io.B)[idx];
+        __builtin_amdgcn_sched_barrier(0);
+        warm_scalar_cache(pp, tail);
+        __builtin_amdgcn_sched_barrier(0);
+        const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
+        const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
+        const bool dist_in_rec = lw <= 16;
+        const bool bad = is_agent && (act < 0 || act > 4);
+        const uint64_t badm = __ballot(bad);
+        const bool errored = badm != 0;
+        const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+        const bool live = is_agent && a < n_live;
+        if (!live) act = 0;
+        MAPF_STAMP_W2(21);
+        wg_sync();  // B1
+        __builtin_amdgcn_s_setprio(1);
+        MAPF_STAMP_W2(22);
+        Lane st;
+        lane_unpack(raw, is_agent, st);
+        const uint4 ent = l.tab[a];
+        const uint32_t old = st.pos, cur = is_agent ? (ent.x >> 16) : (uint32_t)kIdleCell;
+        const uint32_t goal_new = is_agent ? (ent.y & 0xFFFFu) : (uint32_t)kIdleGoal;
+        sc[MAPF_CTR_STEP_COUNT] += 1;  // MA-env:475
+        const bool on_goal = live && cur == st.goal;
+        const WideEnd dec = wide_decide<K>(p, io, N, on_goal, is_agent, errored, sc[MAPF_CTR_STEP_COUNT], nsg);
+        // goal / reward flags (MA-env:538-563)
+        const bool moved = cur != old;
+        bool reached = (st.flags & kFlagReached) != 0, completed = (st.flags & kFlagCompleted) != 0;
+        bool grs = false;
+        if (on_goal && (lifelong || !reached)) {
+            grs = true;
+            completed = true;
+            reached = !lifelong;  // lifelong: reached_goal[i] = False after the respawn, _reached_arr never set
+        }
+        const int goals_step = __popcll(__ballot(grs));
+        sc[MAPF_CTR_GOALS_REACHED_TOTAL] += goals_step;  // MA-env:550,563
+        int sc_keep[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) sc_keep[k] = sc[k];
+        const uint32_t goal_before = st.goal;
+        st.goal = goal_new;
+        // lock flags (MA-env:581-594) and distance history
+        const bool cur_on_goal = is_agent && cur == st.goal;
+        const bool prev_on_goal = !lifelong && old == goal_before;
+        const bool progress = lifelong ? grs : (!prev_on_goal && cur_on_goal);
+        const bool failed = act != 0 && !moved;
+        const int dist = cell_l1(cur, st.goal);
+        int delta = 0;
+        bool dl_ok = false, ll_ok = false;
+        if (lock_on) {
+            const int t = sc[MAPF_CTR_HIST_ROWS];
+            const int count = min(t + 1, K::hs(p));
+            dl_ok = count >= dw;
+            ll_ok = count >= lw;
+            st.moved = (st.moved << 1) | (moved ? 1ull : 0ull);  // _append_lock_history_step MA-env:374-387
+            st.failed = (st.failed << 1) | (failed ? 1ull : 0ull);
+            st.progress = (st.progress << 1) | (progress ? 1ull : 0ull);
+            int d_old = dist;
+            if (dist_in_rec) {
+                st.dist.w = (st.dist.w << 8) | (st.dist.z >> 24);
+                st.dist.z = (st.dist.z << 8) | (st.dist.y >> 24);
+                st.dist.y = (st.dist.y << 8) | (st.dist.x >> 24);
+                st.dist.x = (st.dist.x << 8) | (uint32_t)dist;
+                const int ob = lw - 1, od = ob >> 2;
+                const uint32_t wd = od == 0 ? st.dist.x : (od == 1 ? st.dist.y : (od == 2 ? st.dist.z : st.dist.w));
+                if (ll_ok) d_old = (int)((wd >> ((ob & 3) * 8)) & 0xFFu);
+            } else {
+                int16_t *ring = io.dist_ring + (idx0 + min(a, N - 1)) * ring_stride;
+                const int slot_new = t % lw;
+                const int slot_old = (slot_new + 1 == lw) ? 0 : slot_new + 1;
+                if (ll_ok && is_agent) d_old = ring[slot_old];
+                if (is_agent && !errored) ring[slot_new] = (int16_t)dist;
+            }
+            delta = d_old - dist;
+            sc[MAPF_CTR_HIST_ROWS] = t + 1;
+        }
+        if (!lifelong)
+            sc[MAPF_CTR_MAY_FINISH] = (__ballot(is_agent && dist > 1) == 0 || sc[MAPF_CTR_STEP_COUNT] + 1 >= io.steps_per_episode) ? 1 : 0;
+        // neighbour sets (MA-env:389-398) from the occupancy rows after the move: the diamond of radius `nearby` around my
+        // cell, then one index (and delta) lookup per neighbour -- there are few (64 agents on ~3 300 free cells)
+        uint64_t nbr = 0;
+        int sum_delta = delta;
+        bool blocking = false;
+        const int myr = is_agent ? (int)(cur >> 8) : 0, myc = is_agent ? (int)(cur & 255u) : 0;
+        if (lock_on && is_agent) l.dmap[myr * 64 + myc] = (int8_t)delta;  // (|delta| <= 126 on a 64 x 64 grid)
+        {
+            // the diamond as ONE bit mask, row dr at bits (dr + nb) * (2 nb + 1) ..: a lane pops one neighbour per round, and
+            // the rounds a wave runs are the most neighbours any of its agents has (2-3), not a sum over rows
+            const int nb = K::nearby(p), side = 2 * nb + 1;
+            uint64_t m_lo = 0, m_hi = 0;
+#pragma unroll
+            for (int dr = -kRowPad; dr <= kRowPad; dr++) {
+                if (lock_on && abs(dr) <= nb) {
+                    const int span = nb - abs(dr);
+                    uint64_t bits = wide_window(l.occN[myr + dr + kRowPad], myc - span, 2 * span + 1);
+                    if (dr == 0) bits &= ~(1ull << span);  // not myself
+                    const int at = (dr + nb) * side + (nb - span);
+                    if (at < 64) m_lo |= bits << at;
+                    if (at + 2 * span + 1 > 64) m_hi |= at >= 64 ? (bits << (at - 64)) : (bits >> (64 - at));
+                }
+            }
+            if (!is_agent) m_lo = m_hi = 0;
+            const uint64_t irow = l.intent[myr + kRowPad];
+            blocking = is_agent && reached && !moved && ((irow >> (myc & 63)) & 1ull) != 0;  // MA-env:608-623
+            wave_lds_sync();  // (every lane's delta is in the map)
+            while (__any((m_lo | m_hi) != 0)) {
+                // two neighbours per lane and round (their four reads share one LDS round trip)
+                int j[2], dj[2];
+                bool on[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    on[k] = (m_lo | m_hi) != 0;
+                    const int b = !on[k] ? 0 : (m_lo ? (int)__builtin_ctzll(m_lo) : 64 + (int)__builtin_ctzll(m_hi));
+                    if (b < 64) m_lo &= m_lo - 1; else m_hi &= m_hi - 1;
+                    const int dr = b / side - nb, dc = b - (dr + nb) * side - nb;
+                    const int ci = on[k] ? (myr + dr) * 64 + myc + dc : 0;
+                    j[k] = (int)l.ownN[ci];
+                    dj[k] = (int)l.dmap[ci];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    nbr |= on[k] ? (1ull << (j[k] & 63)) : 0ull;
+                    sum_delta += on[k] ? dj[k] : 0;
+                }
+            }
+        }
+        MAPF_STAMP_W2(24);
+        int deadlock = 0, livelock = 0, dl_event = 0, ll_event = 0;
+        if (lock_on) {  // MA-env:400-438: deadlock has priority over livelock
+            const uint64_t mdw = dw >= 64 ? ~0ull : ((1ull << dw) - 1ull);
+            const uint64_t mlw = lw >= 64 ? ~0ull : ((1ull << lw) - 1ull);
+            const uint64_t members = nbr | (1ull << a);
+            const bool focal = is_agent && !cur_on_goal && __popcll(nbr) >= K::min_nbrs(p);
+            const uint64_t prog_dw_nz = __ballot(is_agent && (st.progress & mdw) != 0);
+            const uint64_t moved_dw_nz = __ballot(is_agent && (st.moved & mdw) != 0);
+            const uint64_t fail_dw_nz = __ballot(is_agent && (st.failed & mdw) != 0);
+            const uint64_t prog_lw_nz = __ballot(is_agent && (st.progress & mlw) != 0);
+            const uint64_t moved_lw_nz = __ballot(is_agent && (st.moved & mlw) != 0);
+            const bool dead_me = focal && dl_ok && (members & (prog_dw_nz | moved_dw_nz)) == 0 && (members & fail_dw_nz) != 0;
+            const bool live_me = focal && ll_ok && (members & prog_lw_nz) == 0 && (members & moved_lw_nz) != 0 &&
+                                 sum_delta <= io.eps_floor;
+            deadlock = __ballot(dead_me) != 0;
+            livelock = !deadlock && __ballot(live_me) != 0;
+            const int prev = sc[MAPF_CTR_LOCK_STATE_PREV];
+            dl_event = deadlock && !(prev & 1);  // rising edges MA-env:599-600
+            ll_event = livelock && !(prev & 2);
+            sc[MAPF_CTR_LOCK_STATE_PREV] = deadlock | (livelock << 1);
+            sc[MAPF_CTR_DEADLOCK_STEPS] += deadlock;
+            sc[MAPF_CTR_LIVELOCK_STEPS] += livelock;
+            sc[MAPF_CTR_DEADLOCK_EVENTS] += dl_event;
+            sc[MAPF_CTR_LIVELOCK_EVENTS] += ll_event;
+        }
+        const int blocking_step = __popcll(__ballot(blocking));
+        sc[MAPF_CTR_BLOCKING_COUNT] += blocking_step;
+        MAPF_STAMP_W2(29);
+        const int reached_cnt = __popcll(__ballot(is_agent && reached));
+        const int completed_cnt = __popcll(__ballot(is_agent && completed));
+        if (!errored) {
+            // info (MA-env:627-656) and counters: staged by lane 0, stored as two coalesced runs
+            const int goals_total = lifelong ? sc[MAPF_CTR_GOALS_REACHED_TOTAL] : reached_cnt;
+            const int steps = max(sc[MAPF_CTR_STEP_COUNT], 1);
+            float2 *xi = reinterpret_cast<float2 *>(l.xinfo);
+            uint4 *xs = reinterpret_cast<uint4 *>(l.xinfo + 64);
+            if (a == 0) {
+                xi[0] = make_float2((float)goals_step, (float)goals_total);
+                xi[1] = make_float2((float)blocking_step, (float)sc[MAPF_CTR_BLOCKING_COUNT]);
+                xi[2] = make_float2((float)deadlock, (float)livelock);
+                xi[3] = make_float2((float)dl_event, (float)ll_event);
+                xi[4] = make_float2((float)sc[MAPF_CTR_DEADLOCK_EVENTS], (float)sc[MAPF_CTR_LIVELOCK_EVENTS]);
+                xi[5] = make_float2((float)sc[MAPF_CTR_DEADLOCK_STEPS], (float)sc[MAPF_CTR_LIVELOCK_STEPS]);
+                xi[6] = make_float2((float)completed_cnt / (float)N, (float)goals_total / (float)steps);
+                if (dec.do_reset) {  // a re-placed env stores the counters reset() leaves (MA-env:440-455)
+                    xs[0] = xs[1] = make_uint4(0, 0, 0, 0);
+                    xs[2] = make_uint4(0, sc[MAPF_CTR_EPISODES_DONE] + 1, 1, sc[11]);
+                } else {
+                    xs[0] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+                    xs[1] = make_uint4(sc[4], sc[5], sc[6], sc[7]);
+                    xs[2] = make_uint4(sc[8], sc[9], sc[10], sc[11]);
+                }
+            }
+            wave_lds_sync();
+            if (io.info_all && lane < 7) reinterpret_cast<float2 *>(io.info_all + (size_t)env * MAPF_INFO_ALL)[lane] = xi[lane];
+            if (lane < 3) store_state16(io.scal + (size_t)env * kScalInts + lane * 4, xs[lane]);
+            Lane img = st;
+            if (dec.do_reset) {  // _reset_lock_tracking MA-env:360-372
+                img.moved = img.failed = img.progress = 0ull;
+                img.dist = make_uint4(0, 0, 0, 0);
+            }
+            if (is_agent) store_lane_hist(io.agents, io.bn8, idx0, lane, img);
+        } else {
+            // the reference raised mid-loop (MA-env:502-506): nothing after the loop ran -- history, lock counters and
+            // blocking keep their values; step_count and the goals counted before the exception stay
+            sc_keep[MAPF_CTR_MAY_FINISH] = 1;  // agents before the bad one did move: the hint of the previous step is stale
+            if (a == 0) {
+                store_state16(io.scal + (size_t)env * kScalInts, make_uint4(sc_keep[0], sc_keep[1], sc_keep[2], sc_keep[3]));
+                store_state16(io.scal + (size_t)env * kScalInts + 4, make_uint4(sc_keep[4], sc_keep[5], sc_keep[6], sc_keep[7]));
+                store_state16(io.scal + (size_t)env * kScalInts + 8, make_uint4(sc_keep[8], sc_keep[9], sc_keep[10], sc_keep[11]));
+            }
+        }
+        MAPF_STAMP_W2(30);
+        // episode statistics (src/trainers/callbacks.py:236-345), as step_body
+        if (__builtin_expect(dec.done, 0)) {
+            if (a == 0) {
+                int *acc = p.ep_acc + (size_t)env * MAPF_NUM_EPISODE_ACC;
+                atomicAdd(acc + MAPF_ACC_EPISODES, 1);
+                if (dec.term && !dec.trunc) atomicAdd(acc + MAPF_ACC_SUCCESSES, 1);
+                atomicAdd(acc + MAPF_ACC_GOALS_REACHED, sc[MAPF_CTR_GOALS_REACHED_TOTAL]);
+                atomicAdd(acc + MAPF_ACC_BLOCKING_COUNT, sc[MAPF_CTR_BLOCKING_COUNT]);
+                atomicAdd(acc + MAPF_ACC_DEADLOCK_COUNT, sc[MAPF_CTR_DEADLOCK_EVENTS]);
+                atomicAdd(acc + MAPF_ACC_LIVELOCK_COUNT, sc[MAPF_CTR_LIVELOCK_EVENTS]);
+                atomicAdd(acc + MAPF_ACC_DEADLOCK_STEPS, sc[MAPF_CTR_DEADLOCK_STEPS]);
+                atomicAdd(acc + MAPF_ACC_LIVELOCK_STEPS, sc[MAPF_CTR_LIVELOCK_STEPS]);
+                atomicAdd(acc + MAPF_ACC_COMPLETED_AGENTS, completed_cnt);
+                atomicAdd(acc + MAPF_ACC_EPISODE_STEPS, sc[MAPF_CTR_STEP_COUNT]);
+            }
+        }
+        if (__builtin_expect(dec.slow_reset, 0)) wg_sync();  // B2 (all waves of the workgroup meet)
+#ifdef MAPF_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MAPF_STAMP_W2(31);
+        return;
+    }
+
+    // =================================== state wave ===================================
+    const int step0 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
+    uint32_t nsg = (lifelong || deterministic) ? kSlotInvalid : slots_of(io.scal, io.B)[idx];
+    // Lifelong mode: what a respawn reads from global memory -- the stream state, the free-cell count, and (below, once the
+    // hot plane is here) the row-major ranks of my old cell, my target cell and my goal -- is requested a whole move phase
+    // before it is needed
+    Pcg g_ll;
+    g_ll.shi = g_ll.slo = g_ll.ihi = g_ll.ilo = 0;
+    g_ll.has32 = g_ll.uinteger = 0;
+    int F_ll = 0;
+    if (lifelong) {
+        pcg_load(g_ll, streams_of(io.scal, io.B, N) + (size_t)env * 6);
+        F_ll = free_counts_of(io.scal, io.B, N)[env];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    warm_scalar_cache(pp, tail);
+    __builtin_amdgcn_sched_barrier(0);
+    const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
+    {   // the nine bit rows that start a step empty (4.7 KB at H = 64): under the latency of the loads above
+        uint4 *z = reinterpret_cast<uint4 *>(lds_raw);
+        const int n4 = (kWideCleared * wide_rows(H) * 8 + 15) >> 4;
+        for (int k = lane; k < n4; k += 64) z[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (lane == 0) l.ctl[0] = 0u;
+    }
+    const bool bad = is_agent && (act < 0 || act > 4);
+    const uint64_t badm = __ballot(bad);
+    const bool errored = badm != 0;
+    const int n_live = errored ? (int)__builtin_ctzll(badm) : N;
+    const bool live = is_agent && a < n_live;
+    if (__builtin_expect(errored, 0)) {
+        if (bad && a == n_live) raise_error(p, MAPF_ERR_BAD_ACTION, env, a, act);
+    }
+    if (!live) act = 0;
+    const uint32_t old = is_agent ? (hot.x & 0xFFFFu) : (uint32_t)kIdleCell;
+    uint32_t goal = is_agent ? (hot.x >> 16) : (uint32_t)kIdleGoal;
+    const uint32_t start = hot.y & 0xFFFFu, fl0 = (hot.y >> 16) & 0xFFu, pass = hot.y >> 24;
+    MAPF_STAMP(0);
+    // ---- move phase (MA-env:502-526): "inside the grid and no obstacle" is the agent's pass bit for the action ----
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const bool want = live && act != 0 && ((pass >> ((act - 1) & 3)) & 1u) != 0;
+    const int r_old = (int)(old >> 8), c_old = (int)(old & 255u);
+    const int tr = r_old + dr, tc = c_old + dc;
+    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : kNoCell;
+    int rankOld = 0x7FFFFFFF, rankTgt = 0x7FFFFFFF, rankGoal = 0x7FFFFFFF;
+    if (lifelong && is_agent) {
+        // (global-address-space loads: through the generic pointer of Params they would be FLAT loads, which also count in
+        //  the LDS wait counter -- every LDS read of the move phase would wait for these gathers)
+        const global_u16 *frank = as_global(p.free_rank) + (size_t)env * p.HW;
+        rankOld = (int)frank[r_old * W + c_old];
+        rankTgt = want ? (int)frank[tr * W + tc] : rankOld;
+        rankGoal = (int)frank[(int)(goal >> 8) * W + (int)(goal & 255u)];
+    }
+    MAPF_STAMP(16);
+    // who stands where before the move; who wants which cell.  An or-with-return on the `want` row tells every contender
+    // but the first that its target is contended; those mark the cell in `contb`, which the first one then sees.
+    if (is_agent) {
+        l.ownO[wide_cell(old)] = (uint8_t)a;
+        atomicOr(reinterpret_cast<unsigned long long *>(&l.occO[wide_row(old)]), wide_bit(old));
+    }
+    unsigned long long seen = 0ull;
+    if (want) seen = atomicOr(reinterpret_cast<unsigned long long *>(&l.wantb[tr + kRowPad]), 1ull << (tc & 63));
+    if (want && ((seen >> (tc & 63)) & 1ull)) atomicOr(reinterpret_cast<unsigned long long *>(&l.contb[tr + kRowPad]), 1ull << (tc & 63));
+    wave_lds_sync();
+    uint32_t cur = old;
+    if (__any(want)) {
+        const int trow = want ? tr + kRowPad : kRowPad;
+        const uint64_t orow = l.occO[trow], crow = l.contb[trow];
+        const int occ = (int)l.ownO[want ? tr * 64 + tc : 0];
+        const bool occupied = want && ((orow >> (tc & 63)) & 1ull) != 0;
+        const bool contended = want && ((crow >> (tc & 63)) & 1ull) != 0;
+        uint64_t cont = 0;  // lower-index contenders for my target
+        uint64_t u = __ballot(contended);
+        while (u) {  // typically none, else a handful of agents
+            const int j = (int)__builtin_ctzll(u);
+            u &= u - 1;
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)(contended ? tgt : kNoCell), j);
+            cont |= (want && j < a && tj == tgt) ? (1ull << j) : 0ull;
+        }
+        const uint64_t below = (1ull << a) - 1ull;
+        const uint64_t occ_bit = occupied ? (1ull << (occ & 63)) : 0ull;
+        const uint64_t occ_low = occ_bit & below;       // occupant has a lower index: blocked unless it moved away
+        const bool occ_high = (occ_bit & ~below) != 0;  // occupant has a higher index (its turn comes later): blocked
+        const uint64_t dep = cont | occ_low;
+        bool resolved = !want, mv = false;
+        uint64_t R = __ballot(resolved), M = 0;
+#pragma unroll 1
+        for (int it = 0; it <= N; it++) {
+            if (__all(resolved)) break;
+            if (!resolved && (dep & ~R) == 0) {
+                mv = !(occ_high || (occ_low & ~M) != 0 || (cont & M) != 0);
+                resolved = true;
+            }
+            R = __ballot(resolved);
+            M = __ballot(mv);
+        }
+        cur = mv ? tgt : old;
+    }
+    const bool moved = cur != old;
+    MAPF_STAMP(2);
+    // occupancy after the move, and the cells whose occupancy depends on the observer's turn
+    if (is_agent) {
+        l.ownN[wide_cell(cur)] = (uint8_t)a;
+        atomicOr(reinterpret_cast<unsigned long long *>(&l.occN[wide_row(cur)]), wide_bit(cur));
+        if (moved) {
+            atomicOr(reinterpret_cast<unsigned long long *>(&l.mov[wide_row(old)]), wide_bit(old));
+            atomicOr(reinterpret_cast<unsigned long long *>(&l.mov[wide_row(cur)]), wide_bit(cur));
+        }
+    }
+    // ---- goal logic of the arrivals (MA-env:538-563); lifelong: respawn in agent order (MA-env:284-304) ----
+    bool reached = (fl0 & kFlagReached) != 0, completed = (fl0 & kFlagCompleted) != 0;
+    const bool pressure_prev = (fl0 & kFlagPressure) != 0;
+    const bool on_goal = live && cur == goal;
+    bool grs = false;
+    bool reassigned = false;
+    if (!lifelong) {
+        if (on_goal && !reached) {
+            reached = true;
+            completed = true;
+            grs = true;
+        }
+    } else {
+        const uint64_t arr = __ballot(on_goal);
+        if (arr) {  // wave-uniform, one wave-step in twelve at c5
+            reassigned = true;
+            wave_lds_sync();
+            Pcg g = g_ll;
+            const int F = F_ll;
+            const int rankCur = moved ? rankTgt : rankOld;
+            // index + 1 of the agent standing on my goal cell after (on) / before (oo) its move, 0 = nobody
+            int on = 0, oo = 0;
+            if (is_agent) {
+                const uint64_t nrow = l.occN[wide_row(goal)], orow = l.occO[wide_row(goal)];
+                const int gi = wide_cell(goal);
+                on = ((nrow >> (goal & 63u)) & 1ull) ? (int)l.ownN[gi] + 1 : 0;
+                oo = ((orow >> (goal & 63u)) & 1ull) ? (int)l.ownO[gi] + 1 : 0;
+            }
+            uint64_t u = arr;
+            while (u) {  // respawns happen in agent order, each sees the state "at time i" (MA-env:554)
+                const int i = (int)__builtin_ctzll(u);
+                u &= u - 1;
+                // occupied cells at time i; goals of everybody else (own old goal is released first, MA-env:286-288)
+                const bool Gact = is_agent && a != i;
+                const int rankP = (a <= i) ? rankCur : rankOld;
+                const int rankG = Gact ? rankGoal : 0x7FFFFFFF;
+                bool dup = (on != 0 && on - 1 <= i) || (oo != 0 && oo - 1 > i);  // my goal cell is also occupied -> count it once
+                dup = dup && Gact;
+                const int overlap = __popcll(__ballot(dup));
+                const int k = F - N - (N - 1) + overlap;  // candidate_indices.size MA-env:295
+                uint32_t r = 0;
+                if (k <= 0) {
+                    if (a == i) raise_error(p, MAPF_ERR_NO_RESPAWN, env, i, k);
+                } else {
+                    bool stuck = false;
+                    r = pcg_bounded(g, (uint32_t)(k - 1), stuck);  // rng.integers(k) MA-env:300
+                    if (stuck && a == i) raise_error(p, MAPF_ERR_RNG_GUARD, env, i, k);
+                }
+                // r-th candidate in row-major order = free-rank y with y = r + #{excluded ranks <= y}
+                int y = (int)r;
+                for (int it = 0; it <= 2 * N; it++) {  // converges in <= #excluded + 1 rounds
+                    const int cnt = __popcll(__ballot(is_agent && rankP <= y)) + __popcll(__ballot(Gact && !dup && rankG <= y));
+                    const int y2 = (int)r + cnt;
+                    const bool changed = k > 0 && y2 != y;
+                    y = y2;
+                    if (!changed) break;
+                }
+                if (k > 0) {
+                    // who stands on the chosen cell later in this step (it is free of agents at time i, not after)
+                    const uint64_t bc = __ballot(is_agent && rankCur == y);
+                    const uint64_t bo = __ballot(is_agent && rankOld == y);
+                    if (a == i) {
+                        goal = as_global(p.free_cells)[(size_t)env * p.HW + y];  // MA-env:301-303
+                        rankGoal = y;
+                        on = bc ? (int)__builtin_ctzll(bc) + 1 : 0;
+                        oo = bo ? (int)__builtin_ctzll(bo) + 1 : 0;
+                    }
+                }
+            }
+            if (a == 0) pcg_store(g, p.rng + (size_t)env * 6);
+            g_ll = g;
+            if (on_goal) {  // MA-env:547-556
+                grs = true;
+                completed = true;
+                reached = false;
+            }
+        }
+    }
+    // goals (after the respawns) and intents (MA-env:608-623: intended_next of the agents that have not reached their goal)
+    if (is_agent) {
+        atomicOr(reinterpret_cast<unsigned long long *>(&l.goalb[wide_row(goal)]), wide_bit(goal));
+        if (!errored && !reached && tr >= 0 && tr < H && tc >= 0 && tc < W)
+            atomicOr(reinterpret_cast<unsigned long long *>(&l.intent[tr + kRowPad]), 1ull << (tc & 63));
+    }
+    l.tab[a] = make_uint4(old | (cur << 16), goal | ((grs ? 1u : 0u) << 16), 0u, 0u);
+    if (a == 0) l.ctl[0] = reassigned ? 1u : 0u;
+    wg_sync();  // B1
+    MAPF_STAMP(19);
+    // ---- after the moves: rewards, per-agent info, done flags, the hot plane ----
+    const WideEnd dec = wide_decide<K>(p, io, N, on_goal, is_agent, errored, step0 + 1, nsg);
+    const uint64_t irow = l.intent[wide_row(is_agent ? cur : 0u)];
+    const bool blocking = is_agent && reached && !moved && ((irow >> (cur & 63u)) & 1ull) != 0;
+    if (!errored) {
+        // +1 each when all stand on their goals, -1 at the step limit for an agent off its goal (finite mode), MA-env:668-690
+        const float term_reward = !(dec.term | dec.trunc) ? 0.0f : (!dec.trunc ? 1.0f : ((lifelong || on_goal) ? 0.0f : -1.0f));
+        const float reward = (grs ? 0.5f : 0.0f) + term_reward;
+        if (is_agent) {
+            if (io.rewards) io.rewards[idx0 + a] = reward;
+            if (io.info_agent) {
+                uchar2 ia;
+                ia.x = blocking ? 1 : 0;
+                ia.y = grs ? 1 : 0;
+                reinterpret_cast<uchar2 *>(io.info_agent)[idx0 + a] = ia;
+            }
+        }
+        if (a == 0) {
+            if (io.terminated) io.terminated[env] = (uint8_t)dec.term;
+            if (io.truncated) io.truncated[env] = (uint8_t)dec.trunc;
+        }
+    }
+    Lane img;
+    img.pos = cur;
+    img.goal = goal;
+    img.start = start;
+    img.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) |
+                ((errored ? pressure_prev : blocking) ? kFlagPressure : 0);
+    img.moved = img.failed = img.progress = 0ull;
+    img.dist = make_uint4(0, 0, 0, 0);
+    if (__builtin_expect(dec.fast_reset, 0)) {  // re-placed from the slot / the fixed starts: the image reset() leaves (MA-env:440-455)
+        const uint32_t rs = deterministic ? (start | (goal << 16)) : nsg;
+        img.start = rs & 0xFFFFu;
+        img.goal = rs >> 16;
+        img.pos = img.start;
+        img.flags = 0u;
+        if (!deterministic && is_agent) slots_of(io.scal, io.B)[idx0 + a] = kSlotInvalid;  // consumed
+    }
+    if (__builtin_expect(dec.slow_reset, 0)) {
+        // ---- the env ends its episode without a pre-drawn placement (lifelong: always): draw inline, MA-env:267-282 ----
+        const bool staged = !lifelong && __ballot(is_agent && a == 0 && slot_word_staged(nsg)) != 0;
+        const uint64_t *rng_src = staged ? p.vis_rng : p.rng;
+        int16_t *hs = l.scratch;
+        const int16_t *out = hs + sample_out_off_i16(N);
+        PcgPre pre{false, {}, 0, {}, {}};
+        if (lifelong) {  // the stream is in registers already (advanced by this step's respawns)
+            pre.have = true;
+            pre.have_j = false;
+            pre.g = g_ll;
+            pre.pop = F_ll;
+        }
+        const bool sampled = sample_starts_goals_parallel<LPE>(p, hs, lane, a, env, true, true, N, rng_src, pre);
+        if (!sampled) {  // F = 2N or a Lemire rejection: the sequential restatement
+            int16_t *outs = hs + p.hash_cap;
+            if (a == 0) {
+                Pcg g;
+                if (lifelong) g = g_ll; else pcg_load(g, rng_src + (size_t)env * 6);
+                const int hash_cap = p.hash_cap, mask = hash_cap - 1, size = 2 * N, pop = p.n_free[env];
+                bool stuck = false;
+                for (int k = 0; k < hash_cap; k++) hs[k] = -1;
+                for (int j = pop - size; j < pop; j++) {  // Floyd
+                    const int val = (int)pcg_bounded(g, (uint32_t)j, stuck);
+                    int loc = val & mask;
+                    for (int pr = 0; hs[loc] != -1 && hs[loc] != val && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                    if (hs[loc] == -1) {
+                        hs[loc] = (int16_t)val;
+                        outs[j - pop + size] = (int16_t)val;
+                    } else {
+                        loc = j & mask;
+                        for (int pr = 0; hs[loc] != -1 && pr < hash_cap; pr++) loc = (loc + 1) & mask;
+                        hs[loc] = (int16_t)j;
+                        outs[j - pop + size] = (int16_t)j;
+                    }
+                }
+                for (int i = size - 1; i >= 1; i--) {  // _shuffle_int tail shuffle
+                    const int j = (int)pcg_bounded(g, (uint32_t)i, stuck);
+                    const int16_t t = outs[j];
+                    outs[j] = outs[i];
+                    outs[i] = t;
+                }
+                if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, 0, 0);
+                pcg_store(g, p.rng + (size_t)env * 6);
+            }
+            wave_lds_sync();
+            out = outs;
+        }
+        uint32_t ns = kIdleCell, ng = kIdleGoal;
+        if (is_agent) {
+            const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+            const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address
+            ns = fc[min(max((int)out[a], 0), top)];
+            ng = fc[min(max((int)out[N + a], 0), top)];
+            atomicOr(reinterpret_cast<unsigned long long *>(&l.occR[wide_row(ns)]), wide_bit(ns));
+            atomicOr(reinterpret_cast<unsigned long long *>(&l.goalR[wide_row(ng)]), wide_bit(ng));
+            if (nsg != kSlotInvalid) slots_of(io.scal, io.B)[idx0 + a] = kSlotInvalid;  // overtaken (staged): Params::rng is the visible stream again
+        }
+        l.tab[a].z = ns | (ng << 16);
+        wg_sync();  // B2
+        img.start = ns;
+        img.goal = ng;
+        img.pos = ns;
+        img.flags = 0u;
+    }
+    if (is_agent) store_lane_hot(io.agents + idx0, (size_t)a, img, wide_pass_bits(l.freeb, img.pos));
+    MAPF_STAMP(8);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MAPF_STAMP(9);
+    MAPF_STAMP_ENTRY_STORE();
 }
 
 // ================================================================================================

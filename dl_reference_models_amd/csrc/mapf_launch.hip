@@ -23,6 +23,11 @@ namespace mapfk {
 // small groups: both register budgets are built (k_step's WPS), the plan says which one its grid needs
 template <class K, int LPE, int MW>
 static hipError_t launch_fixed_step(const LaunchPlan &lp, const Io &io, hipStream_t s) {
+    if constexpr (LPE == 64) {
+        if (lp.wide3)
+            LAUNCH_CHECKED((k_stepw<K, MW>), dim3(lp.blocks + lp.sampler_blocks), dim3(192), lp.wide_lds_bytes, s, lp.d_params,
+                           IO_HEAD_ARGS(io));
+    }
     if constexpr (K::kSlicedDraw && LPE <= 16) {
         if (lp.three_wave)
             LAUNCH_CHECKED((k_step3<K, LPE, MW, 0>), dim3(lp.blocks + lp.sampler_blocks), dim3(192), lp.lds_bytes, s, lp.d_params,

@@ -67,6 +67,8 @@ struct mapf_engine {
     int many_dense = 0;  // the fused launch has more than two waves per SIMD: the 128-register build of k_step_many
     int three_wave = 0;  // k_step3 (state / observation / aux wave): specialised finite shapes with N = 4 or 8, not dense
     int rt_sliced = 0;   // runtime-config kernels with the sliced background draw (KRuntimeSliced): full groups of 4 / 8 agents
+    int wide3 = 0;       // k_stepw: 64-lane groups with the cell-map conditions met step on the three-wave kernel with bit rows
+    int wide_lds_bytes = 0;
     // step kernels compiled for exactly this configuration at mapf_create (MAPF_FLAG_JIT_SPECIALIZE), else null
     hipFunction_t jit_step = nullptr, jit_many = nullptr;
     std::string jit_note = "not requested (MAPF_FLAG_JIT_SPECIALIZE)";
@@ -141,7 +143,7 @@ struct DeviceScope {
     } while (0)
 
 // engine knobs of mapf_config.flags that choose among builds of the same kernel (never part of the env's configuration)
-constexpr uint32_t kKernelChoiceFlags = MAPF_FLAG_FORCE_DENSE | MAPF_FLAG_FORCE_SPARSE | MAPF_FLAG_SAMPLER_WORKGROUPS;
+constexpr uint32_t kKernelChoiceFlags = MAPF_FLAG_FORCE_DENSE | MAPF_FLAG_FORCE_SPARSE | MAPF_FLAG_SAMPLER_WORKGROUPS | MAPF_FLAG_TWO_WAVE_WIDE;
 
 // Development builds only (-DMAPF_DEV): knobs read from the environment for A/B timing.  The shipped library reads
 // MAPF_JIT_CACHE_DIR (and the usual XDG / HOME variables behind it) and nothing else: which kernel a handle runs is a
@@ -182,6 +184,8 @@ LaunchPlan plan_of(const mapf_engine *e) {
     lp.many_dense = e->many_dense;
     lp.three_wave = e->three_wave;
     lp.rt_sliced = e->rt_sliced;
+    lp.wide3 = e->wide3;
+    lp.wide_lds_bytes = e->wide_lds_bytes;
     return lp;
 }
 
@@ -324,8 +328,11 @@ void jit_specialize(mapf_engine *e) {
     char tail_[64];
     snprintf(tail_, sizeof tail_, ", %d, %d", lpe, e->mask_w);
     const int wps = (lpe < 32 && e->dense) ? 4 : 0;
-    const char *step_kernel = e->three_wave ? "k_step3" : "k_step";  // (three_wave implies wps == 0)
-    const std::string step_expr = std::string("mapfjit::") + step_kernel + "<mapfjit::" + inst + tail_ + ", " + std::to_string(wps) + ">";
+    const char *step_kernel = e->wide3 ? "k_stepw" : (e->three_wave ? "k_step3" : "k_step");  // (three_wave implies wps == 0)
+    char wtail[32];
+    snprintf(wtail, sizeof wtail, ", %d>", e->mask_w);  // k_stepw<K, MW>
+    const std::string step_args = e->wide3 ? std::string(inst) + wtail : std::string(inst) + tail_ + ", " + std::to_string(wps) + ">";
+    const std::string step_expr = std::string("mapfjit::") + step_kernel + "<mapfjit::" + step_args;
     const int many_wps = (lpe < 32 && e->many_dense) ? 4 : 0;
     const std::string many_expr = std::string("mapfjit::k_step_many<mapfjit::") + inst + tail_ + ", " + std::to_string(many_wps) + ">";
     const std::string key = std::to_string(c.device) + "|" + step_expr + "|" + many_expr;  // (the module holds both kernels)
@@ -373,8 +380,7 @@ void jit_specialize(mapf_engine *e) {
         }
       if (it == g_jit_cache.end()) {
         std::string src = "#include \"mapf_step.h\"\n#include \"mapf_kernels.inl\"\nnamespace mapfjit {\n";
-        src += std::string("template __global__ void ") + step_kernel + "<" + inst + tail_ + ", " + std::to_string(wps) +
-               ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);\n";
+        src += std::string("template __global__ void ") + step_kernel + "<" + step_args + "(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail);\n";
         src += std::string("template __global__ void k_step_many<") + inst + tail_ + ", " + std::to_string(many_wps) +
                ">(const Params *, MAPF_IO_HEAD_PARAMS, const IoTail, const int, const int, const ManyPolicy);\n}\n";
         void *prog = nullptr;
@@ -441,8 +447,8 @@ hipError_t launch_jit_step(const mapf_engine *e, const Io &io, hipStream_t s) {
     IoTail tail = static_cast<const IoTail &>(io);
     Io h = io;
     void *args[] = {&pp, &h.agents, &h.scal, &h.grid_rows, &h.actions, &h.B, &h.H, &h.W, &h.bn8, &tail};
-    return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, e->three_wave ? 192 : step_threads(e->lpe), 1, 1,
-                                 e->lds_bytes, s, args, nullptr);
+    return hipModuleLaunchKernel(e->jit_step, e->blocks + e->sampler_blocks, 1, 1, (e->three_wave || e->wide3) ? 192 : step_threads(e->lpe), 1, 1,
+                                 e->wide3 ? e->wide_lds_bytes : e->lds_bytes, s, args, nullptr);
 }
 hipError_t launch_jit_many(const mapf_engine *e, const Io &io, int T, int obs_mode, const ManyPolicy &pol, hipStream_t s) {
     const Params *pp = e->d_params;
@@ -803,6 +809,19 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (e->lds_bytes > 64 * 1024) {
         delete e;
         return fail(nullptr, MAPF_ERR_CONFIG, "config needs more than 64 KiB of LDS per wavefront");
+    }
+    // 64-lane groups (one env per wavefront) whose configuration allows the cell-map path step on k_stepw: one env per
+    // three-wave workgroup, bit rows instead of the word-per-cell map (mapf_kernels.inl).  Reset / observe / fused launches
+    // keep the layout above.
+    if (e->use_map && lpe == 64 && !(c.flags & MAPF_FLAG_TWO_WAVE_WIDE)) {
+        e->wide3 = 1;
+        e->wide_lds_bytes = wide_lds_bytes(H, N * p.L, scratch_i16_alloc);
+        e->sampler_blocks = 0;
+        if (finite_sampled) {
+            e->sampler_blocks = sampler_blocks_for(B, 3);
+            const int need = 3 * sampler_lds_bytes_per_wave(1, p.scratch_i16);
+            if (e->wide_lds_bytes < need) e->wide_lds_bytes = need;
+        }
     }
 
     const int rc = alloc_device_state(e);
@@ -1601,7 +1620,7 @@ int mapf_debug_slots(mapf_handle e, uint32_t *slots, uint32_t *stage, uint64_t *
 int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env) {
     if (!e) return MAPF_ERR_CONFIG;
     if (blocks) *blocks = e->blocks;
-    if (threads) *threads = e->three_wave ? 192 : step_threads(e->lpe);  /* step kernels: state wave + observation wave (+ aux wave) */
+    if (threads) *threads = (e->three_wave || e->wide3) ? 192 : step_threads(e->lpe);  /* step kernels: state wave + observation wave (+ aux wave) */
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (lanes_per_env) *lanes_per_env = e->lpe;
     return e->special;  /* >= 0: id of the compile-time specialisation in use (0 = runtime-config kernel) */

@@ -111,6 +111,8 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_FORCE_SPARSE
     if cfg.get("background_draw") == "sampler_workgroups":
         f |= L.FLAG_SAMPLER_WORKGROUPS
+    if cfg.get("wide_kernel") == "two_wave":  # engine knob: 64-lane groups on the two-wave kernel with the LDS cell map
+        f |= L.FLAG_TWO_WAVE_WIDE
     return f
 
 

@@ -76,6 +76,8 @@ extern "C" {
 #define MAPF_FLAG_FORCE_SPARSE 0x04000000u  /* engine knob (tests): never the 128-register builds */
 #define MAPF_FLAG_SAMPLER_WORKGROUPS 0x02000000u /* engine knob (tests): the runtime-config kernels pre-draw placements in
                                              * sampler workgroups of the step grid instead of slices inside the env workgroups */
+#define MAPF_FLAG_TWO_WAVE_WIDE 0x00800000u /* engine knob (tests / A-B): 64-lane groups step on the two-wave kernel with the
+                                             * word-per-cell LDS map (rounds 1-3) instead of the three-wave kernel with bit rows */
 #define MAPF_FLAG_SEQUENTIAL_RESET 0x20000000u /* engine knob (tests): in-kernel resets always take the sequential
                                                  * sampler (otherwise only after a Lemire rejection or when F = 2N) */
 #define MAPF_FLAG_NO_CELL_MAP 0x40000000u   /* engine knob (tests / A-B): never use the LDS cell-map path of wide groups */

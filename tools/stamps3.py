@@ -42,8 +42,9 @@ rel = full - full[:, :, 15:16]
 names = {4: "W0 first 16 B of records + actions", 5: "W0 whole records", 0: "W0 state in registers (stamp 0)", 16: "W0 target cell known", 2: "W0 moves resolved", 19: "W0 past B1", 3: "W0 goal logic + blocking done",
          17: "W0 rewards / flags issued", 18: "W0 records issued", 8: "W0 body done", 9: "W0 stores drained",
          10: "W1 rows in LDS", 11: "W1 past B1", 12: "W1 observation staged", 13: "W1 stream issued", 14: "W1 stream drained",
+         25: "W1 window rows in registers", 26: "W1 window masks built", 27: "W1 turn-dependent cells resolved",
          21: "W2 state in registers", 22: "W2 past B1", 24: "W2 rewards / flags / hot plane issued", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
-order = [0, 16, 2, 19, 8, 9, 10, 11, 12, 13, 14, 21, 22, 24, 29, 30, 31]
+order = [0, 16, 2, 19, 8, 9, 10, 11, 25, 26, 27, 12, 13, 14, 21, 22, 24, 29, 30, 31]
 print(f"workload {name} ({'staggered' if stagger else 'synchronised'}): {blocks} workgroups x {info['threads']} threads; cycles after the state wave's entry")
 end = np.max(np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]]), axis=0)
 slow = end.argmax(axis=1)

@@ -1,19 +1,18 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase wave time of k_step from in-kernel s_memtime stamps.
 
-Builds a SEPARATE library with -DMAPF_STAMPS (never the shipped one), runs the c3 workload and prints
+Builds a SEPARATE library with -DMAPF_STAMPS (never the shipped one; MAPF_STAMPS_VARIANT = a build.py variant), runs the workload and prints
 the median cycles each phase takes.  Shares only; the stamped build's run time is not representative.
 """
 import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.environ.get("MAPF_STAMPS_LIB") or os.path.join(ROOT, "gpurun_out", "libmapfstep_stamps.so")
-os.makedirs(os.path.dirname(so), exist_ok=True)
-if not os.environ.get("MAPF_STAMPS_LIB"):  # else: a stamps build made beforehand (hipcc cross-compiles without a GPU)
-  subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value",
-                "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DMAPF_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so,
-                os.path.join(ROOT, "dl_reference_models_amd", "csrc", "mapf_step.hip")], check=True)
+so = os.environ.get("MAPF_STAMPS_LIB") or os.path.join(ROOT, "build_diag", "libstamps.so")
+if not os.environ.get("MAPF_STAMPS_LIB"):  # else: a stamps build made beforehand (hipcc cross-compiles without a GPU):
+    # python -m dl_reference_models_amd.build --variant dev_c5 -DMAPF_STAMPS --out build_diag/libstamps_c5.so
+    from dl_reference_models_amd import build as hip_build
+    hip_build.build_variants([os.environ.get("MAPF_STAMPS_VARIANT", "full")], extra=["-DMAPF_STAMPS"], out=so)
 os.environ["MAPF_LIB"] = so
 import torch
 from dl_reference_models_amd import workloads as wl
