@@ -172,6 +172,8 @@ struct IoTail {
     // Params they are generic and their loads (flat_*) would sit in the LDS wait counter of the observation wave
     uint32_t *stage_vals;
     const uint16_t *free_cells;
+    const uint16_t *free_rank;   // (k_stepw's lifelong respawn: ranks are gathered before the move phase, and a pointer read out
+                                 //  of Params would be one more scalar round trip in front of those loads)
     uint64_t *vis_rng;
     const uint64_t *jump_c;      // [B][32][2] per env: S_q * inc mod 2^128 (hi, lo), q = 1 .. 32 -- the increment of a
                                  // PCG64 stream never changes, so this half of the jump-ahead (state_q = A_q * state +
@@ -2077,7 +2079,7 @@ __device__ __forceinline__ bool step_body(const Params &p, const Io &io, const L
         const uint16_t *frank = p.free_rank + (size_t)env * p.HW;
         if (is_agent) {
             rankOld = (int)frank[r_old * W + c_old];
-            rankTgt = want ? (int)frank[tr * W + tc] : rankOld;
+            rankTgt = (int)frank[want ? tr * W + tc : r_old * W + c_old];  // (independent of the load above: no wait here)
             rankGoal = (int)frank[(st.goal >> 8) * W + (st.goal & 255u)];
         }
     }
@@ -3993,8 +3995,8 @@ __global__ __launch_bounds__(many_threads(LPE), (WPS ? WPS : 1)) void k_step_man
 // ================================================================================================
 typedef const __attribute__((address_space(1))) uint16_t global_u16;
 __device__ __forceinline__ global_u16 *as_global(const uint16_t *q) { return (global_u16 *)q; }
-constexpr int kWideBitmaps = 10;       // occO occN mov goalb intent wantb contb occR goalR (cleared at entry) + freeb
-constexpr int kWideCleared = 9;
+constexpr int kWideBitmaps = 9;        // occO occN mov goalb intent wantb (cleared at entry), occR goalR (cleared by whoever
+constexpr int kWideCleared = 6;        // re-places the env), freeb (written whole)
 constexpr int kWideOwnBytes = 64 * 64;  // byte maps are indexed row * 64 + col
 __host__ __device__ constexpr int wide_rows(int H) { return H + 2 * kRowPad; }
 __host__ __device__ constexpr int wide_lds_bytes(int H, int NL, int scratch_i16) {
@@ -4002,7 +4004,7 @@ __host__ __device__ constexpr int wide_lds_bytes(int H, int NL, int scratch_i16)
            64 /* ctl */ + 1024 /* gd_lut */ + 128 /* xinfo */ + ((NL * 4 + 15) & ~15) + ((scratch_i16 * 2 + 15) & ~15);
 }
 struct WideLds {
-    uint64_t *occO, *occN, *mov, *goalb, *intent, *wantb, *contb, *occR, *goalR, *freeb;  // row r at index r + kRowPad
+    uint64_t *occO, *occN, *mov, *goalb, *intent, *wantb, *occR, *goalR, *freeb;  // row r at index r + kRowPad
     uint8_t *ownO, *ownN;  // agent index on a cell before / after the move; valid where occO / occN has the bit
     uint4 *tab;            // per agent: x old | new << 16, y goal (after a respawn) | arrived << 16, z reset placement
     int8_t *dmap;          // per CELL: goal-distance delta (livelock window) of the agent standing there after the move (the aux
@@ -4018,7 +4020,7 @@ __device__ __forceinline__ WideLds carve_wide(unsigned char *raw, int H, int NL)
     const int rs = wide_rows(H);
     uint64_t *b = reinterpret_cast<uint64_t *>(raw);
     l.occO = b; l.occN = b + rs; l.mov = b + 2 * rs; l.goalb = b + 3 * rs; l.intent = b + 4 * rs; l.wantb = b + 5 * rs;
-    l.contb = b + 6 * rs; l.occR = b + 7 * rs; l.goalR = b + 8 * rs; l.freeb = b + 9 * rs;
+    l.occR = b + 6 * rs; l.goalR = b + 7 * rs; l.freeb = b + 8 * rs;
     unsigned char *q = raw + ((kWideBitmaps * rs * 8 + 15) & ~15);
     l.ownO = q; q += kWideOwnBytes;
     l.ownN = q; q += kWideOwnBytes;
@@ -4210,10 +4212,6 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
         sampler_wave<K, LPE>(p, io, lds_raw + wv * sampler_lds_bytes_per_wave(1, p.scratch_i16), si * 3 + wv, lane, io.B + si);
         return;
     }
-    // mapf_step_masked: nothing of a masked-out env is touched (all three waves leave before any barrier)
-    if (__builtin_expect(io.env_mask != nullptr, 0)) {
-        if (io.env_mask[env] == 0) return;
-    }
     const bool is_agent = a < N;
     const size_t idx0 = (size_t)env * N;
     const size_t idx = idx0 + min(a, N - 1);
@@ -4222,6 +4220,24 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
     // every wave reads the hot plane and the actions itself (512 + 64 bytes): no wave waits for another one's loads
     const uint2 hot = io.agents[idx];
     int act = (int)io.actions[idx];
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef MAPF_STAMPS
+    {   // (stamps build: which SIMD of which CU this wave runs on -- HW_REG_HW_ID -- in slots 3 / 4 / 5 of the workgroup's row)
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (p.dbg && lane == 0) p.dbg[(size_t)env * kDbgRow + 3 + wv] = (unsigned long long)hwid | ((unsigned long long)(xcc & 0xFu) << 32);
+    }
+#endif
+    // mapf_step_masked: nothing of a masked-out env is touched -- all three waves leave before any barrier or store.  The mask
+    // pointer is not among the preloaded arguments: each wave looks at it once ALL its loads are out (in front of them, the
+    // wait for the kernel-argument tail delayed every later load of the wave by that round trip).
+#define MAPF_WIDE_MASK_CHECK()                                   \
+    do {                                                         \
+        if (__builtin_expect(io.env_mask != nullptr, 0)) {       \
+            if (io.env_mask[env] == 0) return;                   \
+        }                                                        \
+    } while (0)
 
     if (wv == 1) {
         // =================================== observation wave ===================================
@@ -4231,6 +4247,8 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
         const int step1 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
+        MAPF_WIDE_MASK_CHECK();
+        wg_sync();  // B0 (this wave has nothing to wait for here: the state wave must not find it missing)
         const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
         {   // goal-delta quotients (MA-env:330-335) of every delta a <= 64 x 64 grid has, correctly rounded divide, computed
             // under the latency of the loads above
@@ -4281,6 +4299,7 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
             if (io.obs) {
                 uint32_t place = rs;
                 if (dec.fast_reset) {  // the placement is known here: its bit rows are built by this wave
+                    for (int k = lane; k < 2 * wide_rows(H); k += 64) l.occR[k] = 0ull;  // (occR and goalR, adjacent)
                     if (is_agent) {
                         atomicOr(reinterpret_cast<unsigned long long *>(&l.occR[wide_row(rs & 0xFFFFu)]), wide_bit(rs & 0xFFFFu));
                         atomicOr(reinterpret_cast<unsigned long long *>(&l.goalR[wide_row(rs >> 16)]), wide_bit(rs >> 16));
@@ -4297,6 +4316,7 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
 #ifdef MAPF_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MAPF_STAMP_W1(14);
+        if (p.dbg && threadIdx.x == 64) p.dbg[(size_t)env * kDbgRow + 6] = _t_entry;
 #endif
         return;
     }
@@ -4312,7 +4332,15 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
         __builtin_amdgcn_sched_barrier(0);
         warm_scalar_cache(pp, tail);
         __builtin_amdgcn_sched_barrier(0);
+        MAPF_WIDE_MASK_CHECK();
         const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
+        {   // the six bit rows that start a step empty (3.5 KB at H = 64), under the latency of this wave's loads: done by
+            // the state wave it was 0.5 k cycles on the path every other phase waits for
+            uint4 *z = reinterpret_cast<uint4 *>(lds_raw);
+            const int n4 = (kWideCleared * wide_rows(H) * 8 + 15) >> 4;
+            for (int k = lane; k < n4; k += 64) z[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        wg_sync();  // B0
         const int lw = K::lw(p), dw = K::dw(p), ring_stride = K::ring_stride(p);
         const bool dist_in_rec = lw <= 16;
         const bool bad = is_agent && (act < 0 || act > 4);
@@ -4527,13 +4555,19 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
         if (__builtin_expect(dec.slow_reset, 0)) wg_sync();  // B2 (all waves of the workgroup meet)
 #ifdef MAPF_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.dbg && threadIdx.x == 128) p.dbg[(size_t)env * kDbgRow + 7] = _t_entry;
 #endif
         MAPF_STAMP_W2(31);
         return;
     }
 
     // =================================== state wave ===================================
-    const int step0 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT];
+    // The step counter, the stream and the free-cell count are wave-uniform, but they are fetched with VECTOR loads (an
+    // opaque per-lane zero in the address): scalar loads return out of order and share their counter with LDS, so every
+    // LDS result of the move phase would wait for the slowest of them (measured: -2 % of the c5 step)
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const int step0 = io.scal[(size_t)env * kScalInts + MAPF_CTR_STEP_COUNT + vz];
     uint32_t nsg = (lifelong || deterministic) ? kSlotInvalid : slots_of(io.scal, io.B)[idx];
     // Lifelong mode: what a respawn reads from global memory -- the stream state, the free-cell count, and (below, once the
     // hot plane is here) the row-major ranks of my old cell, my target cell and my goal -- is requested a whole move phase
@@ -4543,19 +4577,14 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
     g_ll.has32 = g_ll.uinteger = 0;
     int F_ll = 0;
     if (lifelong) {
-        pcg_load(g_ll, streams_of(io.scal, io.B, N) + (size_t)env * 6);
-        F_ll = free_counts_of(io.scal, io.B, N)[env];
+        pcg_load(g_ll, streams_of(io.scal, io.B, N) + (size_t)env * 6 + vz);
+        F_ll = free_counts_of(io.scal, io.B, N)[env + vz];
     }
     __builtin_amdgcn_sched_barrier(0);
     warm_scalar_cache(pp, tail);
     __builtin_amdgcn_sched_barrier(0);
+    MAPF_WIDE_MASK_CHECK();
     const WideLds l = carve_wide(lds_raw, H, N * K::L(p));
-    {   // the nine bit rows that start a step empty (4.7 KB at H = 64): under the latency of the loads above
-        uint4 *z = reinterpret_cast<uint4 *>(lds_raw);
-        const int n4 = (kWideCleared * wide_rows(H) * 8 + 15) >> 4;
-        for (int k = lane; k < n4; k += 64) z[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (lane == 0) l.ctl[0] = 0u;
-    }
     const bool bad = is_agent && (act < 0 || act > 4);
     const uint64_t badm = __ballot(bad);
     const bool errored = badm != 0;
@@ -4580,36 +4609,52 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
     if (lifelong && is_agent) {
         // (global-address-space loads: through the generic pointer of Params they would be FLAT loads, which also count in
         //  the LDS wait counter -- every LDS read of the move phase would wait for these gathers)
-        const global_u16 *frank = as_global(p.free_rank) + (size_t)env * p.HW;
+        const uint16_t *frank = io.free_rank + (size_t)env * (H * W);  // (a kernel argument: global address space, no wait)
+        // (three independent loads: `want ? frank[target] : rankOld` made the second one wait for the first -- a global
+        //  round trip in front of the move phase of every step, 0.9 k cycles in the stamps)
         rankOld = (int)frank[r_old * W + c_old];
-        rankTgt = want ? (int)frank[tr * W + tc] : rankOld;
+        rankTgt = (int)frank[want ? tr * W + tc : r_old * W + c_old];
         rankGoal = (int)frank[(int)(goal >> 8) * W + (int)(goal & 255u)];
     }
     MAPF_STAMP(16);
-    // who stands where before the move; who wants which cell.  An or-with-return on the `want` row tells every contender
-    // but the first that its target is contended; those mark the cell in `contb`, which the first one then sees.
+    wg_sync();  // B0: the aux wave has cleared the bit rows (it and the observation wave arrive long before this wave's loads)
+    // Who stands where before the move; who wants which cell -- ONE LDS round trip: the byte map and the occupancy row are
+    // written, the `want` row is or-ed WITH RETURN (every contender for a cell but the first sees the bit set), and the
+    // reads of the target's occupancy follow in the same batch (a wave's DS operations execute in order).
     if (is_agent) {
         l.ownO[wide_cell(old)] = (uint8_t)a;
         atomicOr(reinterpret_cast<unsigned long long *>(&l.occO[wide_row(old)]), wide_bit(old));
+        atomicOr(reinterpret_cast<unsigned long long *>(&l.goalb[wide_row(goal)]), wide_bit(goal));  // (a respawn below puts it right)
     }
     unsigned long long seen = 0ull;
     if (want) seen = atomicOr(reinterpret_cast<unsigned long long *>(&l.wantb[tr + kRowPad]), 1ull << (tc & 63));
-    if (want && ((seen >> (tc & 63)) & 1ull)) atomicOr(reinterpret_cast<unsigned long long *>(&l.contb[tr + kRowPad]), 1ull << (tc & 63));
     wave_lds_sync();
     uint32_t cur = old;
     if (__any(want)) {
-        const int trow = want ? tr + kRowPad : kRowPad;
-        const uint64_t orow = l.occO[trow], crow = l.contb[trow];
+        const uint64_t orow = l.occO[want ? tr + kRowPad : kRowPad];
         const int occ = (int)l.ownO[want ? tr * 64 + tc : 0];
         const bool occupied = want && ((orow >> (tc & 63)) & 1ull) != 0;
-        const bool contended = want && ((crow >> (tc & 63)) & 1ull) != 0;
+        const bool later = want && ((seen >> (tc & 63)) & 1ull) != 0;  // somebody registered for my target before me
+        // Contended cells are rare: the later contenders name their targets (one broadcast each), everybody compares; then
+        // the first registrants of those cells -- who saw nothing -- do the same, so that every contender knows all the
+        // lower-index ones.
+        bool contended = later;
         uint64_t cont = 0;  // lower-index contenders for my target
-        uint64_t u = __ballot(contended);
-        while (u) {  // typically none, else a handful of agents
+        uint64_t u = __ballot(later);
+        while (u) {
             const int j = (int)__builtin_ctzll(u);
             u &= u - 1;
-            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)(contended ? tgt : kNoCell), j);
-            cont |= (want && j < a && tj == tgt) ? (1ull << j) : 0ull;
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)tgt, j);
+            const bool same = want && tj == tgt;
+            contended |= same;
+            cont |= (same && j < a) ? (1ull << j) : 0ull;
+        }
+        u = __ballot(contended && !later);
+        while (u) {
+            const int j = (int)__builtin_ctzll(u);
+            u &= u - 1;
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)tgt, j);
+            cont |= (want && tj == tgt && j < a) ? (1ull << j) : 0ull;
         }
         const uint64_t below = (1ull << a) - 1ull;
         const uint64_t occ_bit = occupied ? (1ull << (occ & 63)) : 0ull;
@@ -4717,11 +4762,15 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
                 completed = true;
                 reached = false;
             }
+            // the goal row: every released goal goes out first, then every new one comes in (a new goal may be a cell
+            // that another arrival of this step released)
+            const uint32_t goal_was = hot.x >> 16;
+            if (on_goal) atomicAnd(reinterpret_cast<unsigned long long *>(&l.goalb[wide_row(goal_was)]), ~wide_bit(goal_was));
+            if (on_goal) atomicOr(reinterpret_cast<unsigned long long *>(&l.goalb[wide_row(goal)]), wide_bit(goal));
         }
     }
-    // goals (after the respawns) and intents (MA-env:608-623: intended_next of the agents that have not reached their goal)
+    // intents (MA-env:608-623: intended_next of the agents that have not reached their goal)
     if (is_agent) {
-        atomicOr(reinterpret_cast<unsigned long long *>(&l.goalb[wide_row(goal)]), wide_bit(goal));
         if (!errored && !reached && tr >= 0 && tr < H && tc >= 0 && tc < W)
             atomicOr(reinterpret_cast<unsigned long long *>(&l.intent[tr + kRowPad]), 1ull << (tc & 63));
     }
@@ -4816,6 +4865,7 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
             out = outs;
         }
         uint32_t ns = kIdleCell, ng = kIdleGoal;
+        for (int k = lane; k < 2 * wide_rows(H); k += 64) l.occR[k] = 0ull;  // (occR and goalR, adjacent)
         if (is_agent) {
             const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
             const int top = p.HW - 1;  // idx entries are ranks < F <= HW; the clamp only bounds the address

@@ -1239,6 +1239,7 @@ static int step_impl(mapf_handle e, const int8_t *actions, const uint8_t *env_ma
     io.env_mask = env_mask;
     io.stage_vals = e->d_stage_vals;
     io.free_cells = e->d_free_cells;
+    io.free_rank = e->d_free_rank;
     io.vis_rng = e->d_vis_rng;
     io.jump_c = e->d_jump_c;
     ON_DEVICE(e);

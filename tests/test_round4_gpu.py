@@ -241,3 +241,115 @@ def test_engine_vs_oracle_c5_full_batch():
             _eq(k, ra[k], rb[k], t)
     _eq("goals", eng.goals(), orc.goals())
     _eq("rng words", eng.rng_words(), orc.rng_words())
+
+
+# ---- k_stepw: the three-wave kernel of 64-lane groups ------------------------------------------------------------------
+def _wide_cfg(n, **over):
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "include_action_mask_in_obs": True, "steps_per_episode": 13}
+    cfg.update(over)
+    return cfg
+
+
+@pytest.mark.parametrize("two_wave", [False, True])
+@pytest.mark.parametrize("n,H,W,over", [
+    (64, 64, 64, {"lifelong_mapf": True, "steps_per_episode": 9}),                       # the c5 shape, episodes ending often
+    (40, 20, 21, {"steps_per_episode": 7}),                                               # finite: slots from the sampler workgroups, N < 64
+    (33, 16, 17, {"deterministic": True, "steps_per_episode": 5}),                        # fixed starts: fast reset without a slot
+    (48, 30, 30, {"livelock_window_steps": 40, "deadlock_window_steps": 20, "lifelong_mapf": True}),  # int16 distance ring
+    (36, 12, 12, {"sensor_range": 4, "lock_nearby_manhattan": 4, "lock_min_neighbors": 2, "include_goal_distance": True}),
+    (6, 9, 9, {"lanes_per_env": 64, "steps_per_episode": 4}),                             # a small env forced onto one wavefront
+])
+def test_wide_kernel_and_the_two_wave_kernel_match_the_oracle(n, H, W, over, two_wave):
+    """64-lane groups step on k_stepw (three waves per env, bit rows in LDS) unless the `wide_kernel` knob keeps them on the
+    two-wave kernel with the word-per-cell map: both against the oracle, with and without the terminal observation."""
+    over = dict(over)
+    kw = {"lanes_per_env": over.pop("lanes_per_env")} if "lanes_per_env" in over else {}
+    if two_wave:
+        kw["wide_kernel"] = "two_wave"
+    cfg = _wide_cfg(n, **over)
+    B = 21
+    grids = synth_grids(B, H, W, 0.12, n, base_seed=93_000)
+    seeds = list(range(40, 40 + B))
+    fs = fg = None
+    if cfg.get("deterministic"):
+        rng = np.random.default_rng(3)
+        cells = [np.argwhere(grids[b] == 0) for b in range(B)]
+        pick = [c[rng.permutation(len(c))[: 2 * n]] for c in cells]
+        fs = np.stack([q[:n] for q in pick]).astype(np.int16)
+        fg = np.stack([q[n:] for q in pick]).astype(np.int16)
+    for want_final in (False, True):
+        eng = EngineStepper(grids, cfg, seeds=seeds, fixed_starts=fs, fixed_goals=fg, want_final_obs=want_final, **kw)
+        orc = OracleStepper(grids, cfg, seeds=seeds, fixed_starts=fs, fixed_goals=fg)
+        assert eng.env.launch_info()["threads"] == (128 if two_wave else 192)
+        _eq("reset", eng.reset(), orc.reset())
+        counts = np.arange(B) % int(cfg["steps_per_episode"])
+        eng.set_step_counts(counts)
+        orc.set_step_counts(counts)
+        rng = np.random.default_rng(11)
+        for t in range(45):
+            a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+            ra, rb = eng.step(a), orc.step(a)
+            for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+                _eq(k, ra[k], rb[k], t)
+            done = (rb["terminated"] | rb["truncated"]).astype(bool)
+            if want_final and done.any():
+                _eq("final_obs", ra["final_obs"][done], rb["final_obs"][done], t)
+        _eq("positions", eng.positions(), orc.positions())
+        _eq("goals", eng.goals(), orc.goals())
+        _eq("rng words", eng.rng_words(), orc.rng_words())
+        eng.env.poll_error()
+
+
+def test_wide_kernel_invalid_action_partial_mutation():
+    """MA-env:502-506 at 64 lanes per env: the agents before the bad one are processed (moves, goal logic, lifelong
+    respawns), nothing after the loop runs; the engine latches the error.  State compared with the oracle stopped the
+    same way."""
+    n, B = 40, 5
+    cfg = _wide_cfg(n, lifelong_mapf=True, steps_per_episode=50)
+    grids = synth_grids(B, 14, 15, 0.1, n, base_seed=94_000)
+    seeds = list(range(B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(2)
+    for t in range(6):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        _eq("obs", ra["obs"], rb["obs"], t)
+    a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+    a[2, 17] = 7  # env 2: agents 0 .. 16 are processed, then the reference raises
+    eng.step(a)
+    with pytest.raises(ValueError, match="Invalid action 7 for agent_17"):
+        eng.env.poll_error()
+    for b in range(B):
+        rc, *_ = orc.batch.envs[b].step(a[b].astype(np.int32))
+        assert rc == (orc.orc.ERR_BAD_ACTION if b == 2 else 0)
+    _eq("positions", eng.positions(), orc.positions())
+    _eq("goals", eng.goals(), orc.goals())
+    _eq("rng words", eng.rng_words(), orc.rng_words())
+    st = eng.env.get_state()
+    _eq("step counts", st["counters"][:, 0], np.array([e.step_count for e in orc.batch.envs], np.int32))
+    # and the engine goes on like the reference's env object does after the exception
+    for t in range(5):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "info_all"):
+            _eq(k, ra[k], rb[k], t)
+
+
+def test_wide_kernel_masked_step_leaves_masked_envs_untouched():
+    n, B = 64, 7
+    cfg = _wide_cfg(n, lifelong_mapf=True, steps_per_episode=30)
+    grids = synth_grids(B, 20, 20, 0.1, n, base_seed=95_000)
+    eng = EngineStepper(grids, cfg, seeds=list(range(B)))
+    eng.reset()
+    before = eng.env.get_state()
+    mask = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.uint8, device=eng.env.device)
+    a = torch.from_numpy(np.random.default_rng(1).integers(0, 5, size=(B, n)).astype(np.int8)).to(eng.env.device)
+    a[1, 3] = 9  # garbage in a masked-out row must not latch anything
+    eng.env.step(a, env_mask=mask)
+    eng.env.poll_error()
+    after = eng.env.get_state()
+    for b in (1, 4, 5):
+        for k in before:
+            assert np.array_equal(before[k][b], after[k][b]), (k, b)
+    assert (after["counters"][[0, 2, 3, 6], 0] == 1).all()

@@ -42,9 +42,10 @@ rel = full - full[:, :, 15:16]
 names = {4: "W0 first 16 B of records + actions", 5: "W0 whole records", 0: "W0 state in registers (stamp 0)", 16: "W0 target cell known", 2: "W0 moves resolved", 19: "W0 past B1", 3: "W0 goal logic + blocking done",
          17: "W0 rewards / flags issued", 18: "W0 records issued", 8: "W0 body done", 9: "W0 stores drained",
          10: "W1 rows in LDS", 11: "W1 past B1", 12: "W1 observation staged", 13: "W1 stream issued", 14: "W1 stream drained",
+         6: "W1 wave entry", 7: "W2 wave entry",
          25: "W1 window rows in registers", 26: "W1 window masks built", 27: "W1 turn-dependent cells resolved",
          21: "W2 state in registers", 22: "W2 past B1", 24: "W2 rewards / flags / hot plane issued", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
-order = [0, 16, 2, 19, 8, 9, 10, 11, 25, 26, 27, 12, 13, 14, 21, 22, 24, 29, 30, 31]
+order = [0, 16, 2, 19, 8, 9, 6, 10, 11, 25, 26, 27, 12, 13, 14, 7, 21, 22, 24, 29, 30, 31]
 print(f"workload {name} ({'staggered' if stagger else 'synchronised'}): {blocks} workgroups x {info['threads']} threads; cycles after the state wave's entry")
 end = np.max(np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]]), axis=0)
 slow = end.argmax(axis=1)
@@ -73,3 +74,23 @@ if samp.shape[1]:  # sampler workgroups (their own clock origin: only durations 
         d03 = (samp[:, :, 3] - samp[:, :, 0])[act]
         d12 = (samp[:, :, 2] - samp[:, :, 1])[act]
         print(f"  active sampler wave (wave 0 of its workgroup): draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f}), entry -> stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
+
+if full[:, :, 3].any():  # k_stepw stamps build: HW_REG_HW_ID of the three waves (gfx9: simd_id bits 5:4, cu_id 11:8, sh 12, se 15:13; xcc in the high bits)
+    hw = full[-1, :, 3:6]
+    simd = (hw >> 4) & 3
+    cu = ((hw >> 8) & 0xFF) | ((hw >> 32) << 8)  # cu_id, sh_id, se_id of HW_ID and the XCC id: one value per CU
+    print("  wave placement (last launch): SIMD ids of (W0, W1, W2), first 12 workgroups:", [tuple(int(x) for x in simd[i]) for i in range(12)])
+    same_cu = (cu[:, 0] == cu[:, 1]) & (cu[:, 1] == cu[:, 2])
+    print(f"  workgroups whose three waves report the same CU: {same_cu.mean():.2f}")
+    import collections
+    per = collections.Counter()
+    kinds = collections.defaultdict(list)
+    for w in range(hw.shape[0]):
+        for k in range(3):
+            key = (int(cu[w, k]), int(simd[w, k]))
+            per[key] += 1
+            kinds[key].append(k)
+    cnt = collections.Counter(per.values())
+    print("  waves per (CU, SIMD): histogram", dict(sorted(cnt.items())), " (CU, SIMD) pairs used:", len(per))
+    mix = collections.Counter(tuple(sorted(v)) for v in kinds.values())
+    print("  kinds of waves sharing a SIMD (0 state, 1 obs, 2 aux), most common:", mix.most_common(8))
