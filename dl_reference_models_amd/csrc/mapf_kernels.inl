@@ -4986,43 +4986,182 @@ __device__ __forceinline__ void cte_observe(const CteIo &io, const int N, const 
     cte_overlay<LPE>(io, srow, is_agent, a, pos, goal);
 }
 
-// SA-env:158-191 for the groups with do_reset: one rng.choice(F) (= bounded(F-1)) per attempt, rejection until unique
+// SA-env:158-191 for the groups with do_reset: one rng.choice(F) (= bounded(F-1)) per attempt, rejection until unique.
+// The sequential restatement: one lane, one PCG64 step and one free-cell gather per attempt -- 2N dependent global round
+// trips, ~22 k cycles at N = 4, paid by every launch in which an env of the batch ends its episode (round 3 measured this
+// env at 5.0 us per step with all episodes in phase and never with staggered ones: 13.1 us).
+template <int LPE>
+__device__ __forceinline__ void cte_sample_sequential(const Params &p, const int N, uint16_t *starts, uint16_t *goals, int env) {
+    Pcg g;
+    pcg_load(g, p.rng + (size_t)env * 6);
+    const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
+    const uint32_t top = (uint32_t)(p.n_free[env] - 1);
+    bool gave_up = false, stuck = false;
+    for (int i = 0; i < N && !gave_up; i++) {
+        int guard = 0;
+        for (;; guard++) {
+            const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
+            bool clash = false;
+            for (int j = 0; j < i; j++) clash |= starts[j] == cell;
+            if (!clash) { starts[i] = cell; break; }
+            if (guard > (1 << 20)) { gave_up = true; break; }  // F >= 2N is checked at set_grids; guard only
+        }
+    }
+    for (int i = 0; i < N && !gave_up; i++) {
+        int guard = 0;
+        for (;; guard++) {
+            const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
+            bool clash = false;
+            for (int j = 0; j < i; j++) clash |= goals[j] == cell;
+            for (int j = 0; j < N; j++) clash |= starts[j] == cell;
+            if (!clash) { goals[i] = cell; break; }
+            if (guard > (1 << 20)) { gave_up = true; break; }
+        }
+    }
+    if (gave_up) raise_error(p, MAPF_ERR_FEW_FREE, env, 0, 0);
+    if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, 0, 0);
+    pcg_store(g, p.rng + (size_t)env * 6);
+}
+// The same draw spread over the lanes of the group (round 4).  An attempt is accepted iff its cell has not come up before in
+// the WHOLE sequence of attempts: a start clashes with the earlier starts, a goal with the earlier goals and with every start,
+// and every rejected attempt repeats a value that an earlier attempt had accepted.  So with K = 2N + 8 attempts made at once
+// -- raw outputs by PCG64 jump-ahead (one output = two attempts per lane), all Lemire products and free-cell gathers side by
+// side -- the accepted attempts are the FIRST OCCURRENCES, the first N of them are the starts, the next N the goals, and the
+// stream has advanced by the attempts up to the 2N-th first occurrence.  Fewer than 2N distinct cells among the K attempts,
+// or an attempt Lemire's test might reject (`left < F`, probability F / 2^32), sends the group to the sequential restatement.
+// Group scratch: raw[K + 1] uint32 | cand[K] uint16 | starts[N] | goals[N].
+struct CtePre {  // the stream and the free-cell count of the lane's env, fetched ahead by the caller (lane 0 of each group), or nothing
+    bool have;
+    uint4 w0, w1, w2;  // the six 64-bit stream words
+    int F;
+};
 template <int LPE>
 __device__ __forceinline__ void cte_sample_starts_goals(const Params &p, const int N, int16_t *scratch, int grp, int a,
-                                                        int env, bool do_reset, bool is_agent, Lane &st) {
-    uint16_t *starts = reinterpret_cast<uint16_t *>(scratch + grp * p.scratch_i16);
+                                                        int env, bool do_reset, bool is_agent, Lane &st,
+                                                        const CtePre &pre = CtePre{false, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0}) {
+    const int lane = grp * LPE + a;
+    const int K = 2 * N + 8;
+    uint32_t *raw = reinterpret_cast<uint32_t *>(scratch + grp * p.scratch_i16);
+    uint16_t *cand = reinterpret_cast<uint16_t *>(raw + K + 2);
+    // (K + 2) * 2 + K + 1 + 2N int16 must fit the group's scratch; at most two outputs per lane, jump tables up to 64
+    const bool par = (2 * (K + 2) + ((K + 1) & ~1) + 2 * N) <= p.scratch_i16 && (K + 1) / 2 <= 2 * LPE && (K + 1) / 2 <= 64 &&
+                     !(p.flags & MAPF_FLAG_SEQUENTIAL_RESET);
+    uint16_t *starts = par ? cand + ((K + 1) & ~1) : reinterpret_cast<uint16_t *>(scratch + grp * p.scratch_i16);
     uint16_t *goals = starts + N;
-    if (do_reset && a == 0) {
+    bool ok = do_reset && par;
+    if (__any(ok)) {
         Pcg g;
-        pcg_load(g, p.rng + (size_t)env * 6);
+        g.shi = g.slo = g.ihi = g.ilo = 0;
+        g.has32 = g.uinteger = 0;
+        int F = 2;
+        if (pre.have) {  // fetched with the wave's first loads by lane 0 of the group: one global round trip less behind the episode's end
+            const uint32_t w[12] = {gshfl<LPE>(pre.w0.x, 0), gshfl<LPE>(pre.w0.y, 0), gshfl<LPE>(pre.w0.z, 0), gshfl<LPE>(pre.w0.w, 0),
+                                    gshfl<LPE>(pre.w1.x, 0), gshfl<LPE>(pre.w1.y, 0), gshfl<LPE>(pre.w1.z, 0), gshfl<LPE>(pre.w1.w, 0),
+                                    gshfl<LPE>(pre.w2.x, 0), gshfl<LPE>(pre.w2.y, 0), gshfl<LPE>(pre.w2.z, 0), gshfl<LPE>(pre.w2.w, 0)};
+            const int Fg = (int)gshfl<LPE>((uint32_t)pre.F, 0);
+            if (ok) {
+                g.shi = (uint64_t)w[0] | ((uint64_t)w[1] << 32); g.slo = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+                g.ihi = (uint64_t)w[4] | ((uint64_t)w[5] << 32); g.ilo = (uint64_t)w[6] | ((uint64_t)w[7] << 32);
+                g.has32 = w[8]; g.uinteger = w[10];
+                F = Fg;
+            }
+        } else if (ok) {
+            pcg_load(g, p.rng + (size_t)env * 6);
+            F = p.n_free[env];
+        }
+        const int has = (int)g.has32;
+        const int nout = (K - has + 1) >> 1;  // 64-bit outputs behind the K attempts: [buffered half] lo(o1) hi(o1) lo(o2) ...
+        const U128 s0 = {g.shi, g.slo}, inc = {g.ihi, g.ilo};
+        U128 stq[2] = {s0, s0};
+        uint32_t hiq[2] = {0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int q = a + 1 + r * LPE;
+            if (ok && q <= nout) {
+                const U128 ja = {kPcgJumpA[q][0], kPcgJumpA[q][1]};
+                const U128 js = {kPcgJumpS[q][0], kPcgJumpS[q][1]};
+                stq[r] = add128(mul128(ja, s0), mul128(js, inc));
+                const uint64_t o = pcg_output(stq[r]);
+                hiq[r] = (uint32_t)(o >> 32);
+                raw[has + 2 * (q - 1)] = (uint32_t)o;
+                raw[has + 2 * (q - 1) + 1] = hiq[r];
+            }
+        }
+        if (ok && has && a == 0) raw[0] = g.uinteger;
+        wave_lds_sync();
+        // all attempts at once: bounded draw (Lemire, conservative rejection test) and the gather of its free cell
+        constexpr int kPerLane = 4;  // attempts per lane: K = 2N + 8 <= 2 LPE + 8 <= 4 LPE (LPE >= 4)
         const uint16_t *fc = p.free_cells + (size_t)env * p.HW;
-        const uint32_t top = (uint32_t)(p.n_free[env] - 1);
-        bool gave_up = false, stuck = false;
-        for (int i = 0; i < N && !gave_up; i++) {
-            int guard = 0;
-            for (;; guard++) {
-                const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
-                bool clash = false;
-                for (int j = 0; j < i; j++) clash |= starts[j] == cell;
-                if (!clash) { starts[i] = cell; break; }
-                if (guard > (1 << 20)) { gave_up = true; break; }  // F >= 2N is checked at set_grids; guard only
+        uint32_t rejm = 0;   // bit i: my i-th attempt might be rejected by Lemire's test
+        uint16_t mine[kPerLane];
+#pragma unroll
+        for (int i = 0; i < kPerLane; i++) {
+            const int k = a + i * LPE;
+            mine[i] = 0xFFFFu;
+            if (ok && k < K) {
+                const uint64_t m = (uint64_t)raw[k] * (uint32_t)F;
+                rejm |= ((uint32_t)m < (uint32_t)F) ? (1u << i) : 0u;
+                mine[i] = fc[min((int)(m >> 32), F - 1)];
             }
         }
-        for (int i = 0; i < N && !gave_up; i++) {
-            int guard = 0;
-            for (;; guard++) {
-                const uint16_t cell = fc[pcg_bounded(g, top, stuck)];
-                bool clash = false;
-                for (int j = 0; j < i; j++) clash |= goals[j] == cell;
-                for (int j = 0; j < N; j++) clash |= starts[j] == cell;
-                if (!clash) { goals[i] = cell; break; }
-                if (guard > (1 << 20)) { gave_up = true; break; }
+        wave_lds_sync();
+        // first occurrences: attempt k is one iff no earlier attempt drew the same cell.  Every attempt is broadcast inside
+        // the group once (ds_bpermute: the LDS crossbar, all of them in flight together) and every lane compares it with its
+        // own: as a loop over the LDS copy -- one dependent read per earlier attempt -- this test alone was 3.2 us per reset
+        bool dupf[kPerLane];
+#pragma unroll
+        for (int i = 0; i < kPerLane; i++) dupf[i] = false;
+#pragma unroll
+        for (int r = 0; r < kPerLane; r++) {
+            if (r * LPE < K) {
+#pragma unroll 8
+                for (int j = 0; j < LPE; j++) {
+                    if (r * LPE + j < K) {
+                        const uint32_t cj = gshfl<LPE>((uint32_t)mine[r], j);
+#pragma unroll
+                        for (int i = r; i < kPerLane; i++)  // (attempt r * LPE + j comes before a + i * LPE iff i > r, or i == r and j < a)
+                            dupf[i] |= cj == (uint32_t)mine[i] && (i > r || j < a);
+                    }
+                }
             }
         }
-        if (gave_up) raise_error(p, MAPF_ERR_FEW_FREE, env, 0, 0);
-        if (stuck) raise_error(p, MAPF_ERR_RNG_GUARD, env, 0, 0);
-        pcg_store(g, p.rng + (size_t)env * 6);
+        // their running count in attempt order (rows of LPE attempts), the attempt that completes the draw
+        int accepted_before = 0, used = 0;
+        bool rejected = false;
+#pragma unroll
+        for (int i = 0; i < kPerLane; i++) {
+            const int k = a + i * LPE;
+            const bool dup = dupf[i];
+            const bool first = ok && k < K && !dup;
+            const uint64_t fm = gballot<LPE>(first, lane);
+            const int idx = accepted_before + __popcll(fm & ((1ull << a) - 1ull));
+            if (first && idx < N) starts[idx] = mine[i];
+            if (first && idx >= N && idx < 2 * N) goals[idx - N] = mine[i];
+            const uint64_t lastm = gballot<LPE>(first && idx == 2 * N - 1, lane);
+            if (lastm) used = i * LPE + (int)__builtin_ctzll(lastm) + 1;
+            // a possibly rejected attempt among those consumed (attempts of this row up to the completing one, or the whole row)
+            const uint64_t rj = gballot<LPE>(((rejm >> i) & 1u) != 0, lane);
+            const uint64_t upto = lastm ? ((2ull << __builtin_ctzll(lastm)) - 1ull) : ~0ull;
+            if (used == 0 || lastm) rejected |= (rj & upto) != 0;
+            accepted_before += __popcll(fm);
+        }
+        ok = ok && used > 0 && !rejected;
+        if (ok) {  // the stream after `used` attempts: state of the last output consumed; an unused high half stays buffered
+            const int nused = (used - has + 1) >> 1;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (a + 1 + r * LPE == nused) {
+                    Pcg f;
+                    f.shi = stq[r].hi; f.slo = stq[r].lo; f.ihi = g.ihi; f.ilo = g.ilo;
+                    f.has32 = (uint32_t)(has + 2 * nused - used);
+                    f.uinteger = hiq[r];  // NumPy keeps the last high half in the field even once it has been handed out
+                    pcg_store(f, p.rng + (size_t)env * 6);
+                }
+            }
+        }
     }
+    wave_lds_sync();
+    if (do_reset && !ok && a == 0) cte_sample_sequential<LPE>(p, N, starts, goals, env);
     wave_lds_sync();
     if (do_reset && is_agent) {
         st.start = starts[a];
@@ -5130,10 +5269,32 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
             if (!(fio.obs || fio.final_obs)) continue;
             const uint4 ent = (otab + (t & 1) * 64)[lane];
             const bool ag = (ent.z & kCteWAgent) != 0;
+            const bool any_reset = __any((ent.z & kCteWReset) != 0);
+            if (__builtin_expect(any_reset && fio.final_obs == nullptr && fio.obs != nullptr, 0)) {
+                // An env of the workgroup is re-placed and nobody asked for its terminal observation: ONE pass -- the rows of
+                // the other envs as usual, behind B2 the reset placement over the re-placed env's row, one stream.  (Two passes
+                // -- the step's rows, then B2, overlay and a second stream with its own drain -- were 2.5 us of the 9.1 us a
+                // staggered step took after the draw had been made lane-parallel.)
+                const bool rs0 = (ent.z & kCteWReset) != 0;
+                cte_overlay<LPE>(io, srow, ag && !rs0, a, ent.x, ent.y);
+                wg_sync();  // B2: the placement is in the table
+                const uint4 e2 = (otab + (t & 1) * 64)[lane];
+                cte_overlay<LPE>(io, srow, ag && rs0, a, e2.w & 0xFFFFu, e2.w >> 16);
+                flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, rs0 ? 0 : (int)((ent.z >> kCteWSelShift) & 3u), row_len);
+                if (fused) {  // put the touched cells back (free cells: 0) for the next overlay
+                    wave_lds_sync();
+                    if (ag) {
+                        const uint32_t gq = rs0 ? (e2.w >> 16) : ent.y, pq = rs0 ? (e2.w & 0xFFFFu) : ent.x;
+                        srow[(gq >> 8) * W + (gq & 255u)] = 0.0f;
+                        srow[(pq >> 8) * W + (pq & 255u)] = 0.0f;
+                    }
+                    wave_lds_sync();
+                }
+                continue;
+            }
             cte_overlay<LPE>(io, srow, ag, a, ent.x, ent.y);
             flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, (int)((ent.z >> kCteWSelShift) & 3u), row_len);
-            const bool any_reset = __any((ent.z & kCteWReset) != 0);
-            if (fused) {  // put the touched cells back (free cells: 0) for the next step's overlay
+            if (fused || any_reset) {  // put the touched cells back (free cells: 0) for the next overlay
                 wave_lds_sync();
                 if (ag) {
                     srow[(ent.y >> 8) * W + (ent.y & 255u)] = 0.0f;
@@ -5141,8 +5302,31 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
                 }
                 wave_lds_sync();
             }
-            if (any_reset) wg_sync();  // B2: the state wave re-uses the staging rows for the reset observation
-            if (any_reset && fused) wg_sync();  // B3: ... and is done with them (it cleans up after itself)
+            if (any_reset) {
+                // An env of the workgroup was re-placed: its reset observation is built HERE -- the obstacle floats are in
+                // place, so it is an overlay and a flush -- from the placement the state wave drew while this wave was
+                // streaming the step's rows out (B2: that placement is in the table).  (Round 3: the state wave waited for
+                // this wave's flush, drew, rebuilt the whole row itself and flushed: 13.1 us per step with staggered episodes
+                // against 5.0 in phase.)
+                wg_sync();  // B2
+                const uint4 e2 = (otab + (t & 1) * 64)[lane];
+                const bool rs = ag && (e2.z & kCteWReset) != 0;
+                if (fio.obs) {
+                    cte_overlay<LPE>(io, srow, rs, a, e2.w & 0xFFFFu, e2.w >> 16);
+                    Io f2;
+                    f2.obs = fio.obs;
+                    f2.final_obs = nullptr;
+                    flush_rows<KRuntime, LPE>(f2, stage, lane, env0, ngroups, (e2.z & kCteWReset) != 0 ? 0 : 2, row_len);
+                    if (fused) {
+                        wave_lds_sync();
+                        if (rs) {
+                            srow[(e2.w >> 24) * W + ((e2.w >> 16) & 255u)] = 0.0f;
+                            srow[((e2.w >> 8) & 255u) * W + (e2.w & 255u)] = 0.0f;
+                        }
+                        wave_lds_sync();
+                    }
+                }
+            }
         }
         return;
     }
@@ -5151,6 +5335,19 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
     Lane st;
     uint32_t pass = load_lane_hot(io.agents, idx, is_agent, st);
     int4 sc0 = *reinterpret_cast<const int4 *>(io.scal + (size_t)env * kScalInts);
+    // the env's stream and free-cell count, by lane 0 of each group (52 B per env): a reset's draw then starts without a
+    // global round trip (single-step launches: a fused launch draws from the stream as its own resets leave it)
+    CtePre pre{false, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+    if (!fused && !(p.flags & MAPF_FLAG_DETERMINISTIC)) {
+        pre.have = true;
+        if (a == 0) {
+            const uint4 *rw = reinterpret_cast<const uint4 *>(p.rng + (size_t)env * 6);
+            pre.w0 = rw[0];
+            pre.w1 = rw[1];
+            pre.w2 = rw[2];
+            pre.F = p.n_free[env];
+        }
+    }
     int step_count = sc0.x, blocking_total = sc0.z;
 
     // (the actions of step t + 1 are requested while step t is computed: in a fused launch that load's latency would
@@ -5260,35 +5457,20 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
         step_count = step_now;  // (also when the ValueError fires: SA-env:247 increments first)
 
         if (__any(do_reset)) {
-            if (want_obs) wg_sync();  // B2: the observation wave is done with the staging rows
-            else wave_lds_sync();
+            // the draw runs beside the observation wave's stream (it only touches the group's scratch); the reset observation
+            // is that wave's (it has the obstacle floats in place): the placement goes to it through the table, behind B2
             if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
-                cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
+                cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st, pre);
             if (do_reset) {
                 st.pos = st.start;
                 st.flags = 0;
                 step_count = 0;
                 blocking_total = 0;
             }
-            if (fused ? obs_t != nullptr : io.obs != nullptr) {
-                Io fio;
-                fio.obs = obs_t;
-                fio.final_obs = nullptr;
-                if (fused) {  // the obstacle floats are in place: only the overlay, and its clean-up afterwards
-                    cte_overlay<LPE>(io, srow, is_agent && do_reset, a, st.pos, st.goal);
-                    flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
-                    wave_lds_sync();
-                    if (is_agent && do_reset) {
-                        srow[(st.goal >> 8) * W + (st.goal & 255u)] = 0.0f;
-                        srow[(st.pos >> 8) * W + (st.pos & 255u)] = 0.0f;
-                    }
-                    wave_lds_sync();
-                } else {
-                    cte_observe<LPE>(io, N, myrows, srow, env_ok, is_agent, a, st.pos, st.goal);
-                    flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, do_reset ? 0 : 2, row_len);
-                }
+            if (want_obs) {
+                (otab + (t & 1) * 64)[lane].w = (st.pos & 0xFFFFu) | (st.goal << 16);
+                wg_sync();  // B2
             }
-            if (fused && want_obs) wg_sync();  // B3
         }
         // pass bits of the cell the agent stands on now (the rows are in LDS since the first B1)
         pass = is_agent ? agent_pass_bits(myrows, st.pos, io.col_pad, W) : 0u;

@@ -201,6 +201,12 @@ class VecReferenceModel:
                 for (name, shape, dt), off, sz in zip(shapes, offs, sizes):
                     setattr(self, name, self._out_blob[off:off + sz].view(dt).view(shape))
 
+        self._act_shape = torch.Size((B, N))
+        self._step_fn = self._lib.mapf_step
+        self._step_tail = (self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(), self._truncated.data_ptr(),
+                           self._info_all.data_ptr(), self._info_agent.data_ptr(), None)
+        self._step_out = {"obs": self._obs, "rewards": self._rewards, "terminated": self._terminated, "truncated": self._truncated,
+                          "info_all": self._info_all, "info_agent": self._info_agent, "final_obs": None}
         if self.deterministic:
             # fixed start/goal tables (MA-env:124-132)
             fs, fg = cfg.get("fixed_starts", None), cfg.get("fixed_goals", None)
@@ -273,8 +279,16 @@ class VecReferenceModel:
         counters, statistics, outputs).  actions: int8 [B,N] on the env's device."""
         if actions.dtype != torch.int8 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
-        if tuple(actions.shape) != (self.num_envs, self.num_agents):
-            raise ValueError(f"actions must have shape {(self.num_envs, self.num_agents)}")
+        if actions.shape != self._act_shape:
+            raise ValueError(f"actions must have shape {tuple(self._act_shape)}")
+        if env_mask is None and not want_final_obs:
+            # the common call of a rollout loop: every pointer but the actions' is fixed for the life of the handle, so the
+            # argument tuple is built once (ctypes converts plain ints; the per-call cost is one data_ptr() and the stream)
+            rc = self._step_fn(self._h, actions.data_ptr(), *self._step_tail, 1 if auto_reset else 0,
+                               torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                self._check(rc)
+            return self._step_out
         fo = C.c_void_p(self._final_obs.data_ptr()) if (want_final_obs and auto_reset) else None
         if env_mask is not None:
             env_mask = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
