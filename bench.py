@@ -361,7 +361,8 @@ class _MultiAgentRunner:
         self.action_pool = torch.from_numpy(self.action_pool_np).to(device)
         self._base, self._stride = self.action_pool.data_ptr(), self.b * self.n
         info = self.env.launch_info()
-        self.kernel = "k_step_many" if self.T else ("k_step3" if info["threads"] == 192 else "k_step")
+        three = info["threads"] == 192  # k_step3 (small groups) / k_stepw (64-lane groups): three waves per workgroup
+        self.kernel = "k_step_many" if self.T else (("k_stepw" if info["lanes_per_env"] == 64 else "k_step3") if three else "k_step")
         if self.T:
             B, N, Lo, T = self.b, self.n, self.obs_len, self.T
             from dl_reference_models_amd import _lib as L

@@ -99,6 +99,10 @@ struct mapf_engine {
     uint64_t *d_vis_rng = nullptr;  // [B][6] visible stream state of envs whose placement slot is pending (Params::vis_rng)
     Params *d_params = nullptr;  // device copy of `p`, read by the kernels through a pointer
     unsigned long long *d_dbg = nullptr;  // stamps buffer (diagnostic build only)
+    // mapf_bind_outputs: the caller's output buffers for mapf_step_bound
+    float *b_obs = nullptr, *b_rewards = nullptr, *b_info_all = nullptr;
+    uint8_t *b_terminated = nullptr, *b_truncated = nullptr, *b_info_agent = nullptr;
+    bool bound = false;
 };
 
 namespace {
@@ -1250,6 +1254,21 @@ static int step_impl(mapf_handle e, const int8_t *actions, const uint8_t *env_ma
 int mapf_step(mapf_handle e, const int8_t *actions, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated,
               float *info_all, uint8_t *info_agent, float *final_obs, int32_t auto_reset, void *stream) {
     return step_impl(e, actions, nullptr, obs, rewards, terminated, truncated, info_all, info_agent, final_obs, auto_reset, stream);
+}
+
+int mapf_bind_outputs(mapf_handle e, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated, float *info_all,
+                      uint8_t *info_agent) {
+    if (!e) return MAPF_ERR_CONFIG;
+    e->b_obs = obs; e->b_rewards = rewards; e->b_terminated = terminated; e->b_truncated = truncated;
+    e->b_info_all = info_all; e->b_info_agent = info_agent;
+    e->bound = true;
+    return MAPF_OK;
+}
+
+int mapf_step_bound(mapf_handle e, const int8_t *actions, int32_t auto_reset, void *stream) {
+    if (!e || !e->bound) return fail(e, MAPF_ERR_STATE, "mapf_bind_outputs must be called before mapf_step_bound");
+    return step_impl(e, actions, nullptr, e->b_obs, e->b_rewards, e->b_terminated, e->b_truncated, e->b_info_all, e->b_info_agent,
+                     nullptr, auto_reset, stream);
 }
 
 int mapf_step_masked(mapf_handle e, const int8_t *actions, const uint8_t *env_mask, float *obs, float *rewards,

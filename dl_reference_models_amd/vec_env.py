@@ -202,9 +202,9 @@ class VecReferenceModel:
                     setattr(self, name, self._out_blob[off:off + sz].view(dt).view(shape))
 
         self._act_shape = torch.Size((B, N))
-        self._step_fn = self._lib.mapf_step
-        self._step_tail = (self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(), self._truncated.data_ptr(),
-                           self._info_all.data_ptr(), self._info_agent.data_ptr(), None)
+        self._step_fn = self._lib.mapf_step_bound  # (four arguments per call instead of eleven: mapf_bind_outputs)
+        self._check(self._lib.mapf_bind_outputs(self._h, self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(),
+                                                self._truncated.data_ptr(), self._info_all.data_ptr(), self._info_agent.data_ptr()))
         self._step_out = {"obs": self._obs, "rewards": self._rewards, "terminated": self._terminated, "truncated": self._truncated,
                           "info_all": self._info_all, "info_agent": self._info_agent, "final_obs": None}
         if self.deterministic:
@@ -282,9 +282,9 @@ class VecReferenceModel:
         if actions.shape != self._act_shape:
             raise ValueError(f"actions must have shape {tuple(self._act_shape)}")
         if env_mask is None and not want_final_obs:
-            # the common call of a rollout loop: every pointer but the actions' is fixed for the life of the handle, so the
-            # argument tuple is built once (ctypes converts plain ints; the per-call cost is one data_ptr() and the stream)
-            rc = self._step_fn(self._h, actions.data_ptr(), *self._step_tail, 1 if auto_reset else 0,
+            # the common call of a rollout loop: every pointer but the actions' is fixed for the life of the handle and bound to
+            # it once (mapf_bind_outputs); the per-call cost is one data_ptr(), the stream and a four-argument ctypes call
+            rc = self._step_fn(self._h, actions.data_ptr(), 1 if auto_reset else 0,
                                torch.cuda.current_stream(self.device).cuda_stream)
             if rc != 0:
                 self._check(rc)

@@ -282,6 +282,13 @@ int mapf_cte_step(mapf_handle h, const int8_t *actions, float *obs, double *rewa
 int mapf_cte_step_many(mapf_handle h, int32_t T, const int8_t *actions, float *obs, int32_t obs_mode, double *reward,
                        uint8_t *terminated, uint8_t *truncated, float *info, void *stream);
 
+/* The same step for callers that pay per ARGUMENT (ctypes from a Python rollout loop: ~0.4 us each): the output buffers of
+ * mapf_step are bound to the handle once, mapf_step_bound(h, actions, auto_reset, stream) then is mapf_step with those
+ * pointers and final_obs = NULL.  The buffers stay the caller's; binding again replaces them. */
+int mapf_bind_outputs(mapf_handle h, float *obs, float *rewards, uint8_t *terminated, uint8_t *truncated, float *info_all,
+                      uint8_t *info_agent);
+int mapf_step_bound(mapf_handle h, const int8_t *actions, int32_t auto_reset, void *stream);
+
 /* observation of every agent from the CURRENT state, nothing is modified: what the reference returns when
  * get_obs / get_action_mask / _flatten_observation (MA-env:707-773, :306-328) are called outside step().
  * obs: device float32 [B][N][L]. */

@@ -10,6 +10,7 @@ TAG=${1:?tag}; W=${2:?workload}; EP=${3:-staggered}; T=${4:-0}; shift; shift; sh
 EXTRA="$@"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 KEY=$W; [ "$T" != "0" ] && KEY="$W+fused$T"
+[ -n "$EV_KEY" ] && KEY=$EV_KEY   # (a configuration that differs by extra flags, e.g. c4 on one GPU: --scaling strong --gpus 1)
 O=gpurun_out/ev_$TAG/${KEY}_$EP; rm -rf "$O"; mkdir -p "$O"
 FUSED=""; STEPS="--steps 2000 --warmup 300"; PSTEPS="--steps 200 --warmup 50"
 if [ "$T" != "0" ]; then FUSED="--fused $T"; STEPS="--steps $((T * 20)) --warmup $((T * 3))"; PSTEPS="--steps $((T * 4)) --warmup $T"; fi
