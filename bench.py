@@ -75,6 +75,8 @@ def parse_args(argv=None):
                          "python_api_ms_per_step (VecReferenceModel.step in a Python loop); 0 = skip them")
     ap.add_argument("--kernel-samples", type=int, default=200,
                     help="launches timed one by one with events (isolated launch duration)")
+    ap.add_argument("--lanes-per-env", type=int, default=0,
+                    help="diagnostic: override the engine's choice of lanes per env (config.lanes_per_env reports what ran)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks share the visible GPUs round-robin and meet over gloo "
                          "(the line is marked shared_gpu; not a scaling measurement)")
@@ -424,6 +426,8 @@ class _SingleAgentRunner:
         self.b = len(env_ids)
         cfg = wl.workload_config(name, env_ids)
         cfg["device"] = str(device)
+        if args.lanes_per_env:
+            cfg["lanes_per_env"] = args.lanes_per_env
         self.cfg = cfg
         self.env = VecSingleAgentReferenceModel(cfg)
         self.spe = int(cfg["steps_per_episode"])
@@ -477,7 +481,7 @@ class _SingleAgentRunner:
         self.env.poll_error()
 
     def launch_info(self):
-        return self.env.launch_info()
+        return self.env.launch_info(fused=self.T > 1)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -54,7 +54,7 @@ MAX_DIM, MAX_AGENTS, MAX_SENSOR_RANGE, MAX_LOCK_WINDOW = 64, 64, 5, 64
 EXPORTED_SYMBOLS = (
     "mapf_version", "mapf_obs_len", "mapf_create", "mapf_destroy", "mapf_last_error", "mapf_set_grids",
     "mapf_set_rng_state", "mapf_set_fixed_starts_goals", "mapf_get_state", "mapf_set_state", "mapf_reset",
-    "mapf_step", "mapf_bind_outputs", "mapf_step_bound", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_assign_new_goal", "mapf_get_episode_stats", "mapf_episode_stats_async", "mapf_poll_error", "mapf_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
+    "mapf_step", "mapf_bind_outputs", "mapf_step_bound", "mapf_step_masked", "mapf_step_many", "mapf_step_many_sampled", "mapf_cte_configure", "mapf_cte_reset", "mapf_cte_step", "mapf_cte_step_many", "mapf_observe", "mapf_assign_new_goal", "mapf_get_episode_stats", "mapf_episode_stats_async", "mapf_poll_error", "mapf_launch_info", "mapf_cte_many_launch_info", "mapf_debug_stamps", "mapf_debug_slots", "mapf_jit_status",
 )
 
 
@@ -188,5 +188,7 @@ def load():
     L.mapf_debug_slots.argtypes = [vp, vp, vp, vp]
     L.mapf_launch_info.restype = C.c_int
     L.mapf_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.mapf_cte_many_launch_info.restype = C.c_int
+    L.mapf_cte_many_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _libs[so_path] = L
     return L

@@ -76,6 +76,8 @@ struct mapf_engine {
     int col_pad = 0;   // kRowPad when W <= 64 - 2*kRowPad
     int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
     double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
+    // single-agent env, fused launches (mapf_cte_step_many, T > 1): their own group width and LDS layout (mapf_create)
+    struct CteManyPlan { int lpe = 0, blocks = 0, lds_bytes = 0, tab_off = 0, stage_off = 0, scratch_off = 0; } cte_many;
     int blocks = 0;
     int sampler_blocks = 0;  // k_step only: workgroups appended to the grid that pre-draw next-episode placements
     int lds_bytes = 0;
@@ -669,13 +671,17 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
         return fail(nullptr, MAPF_ERR_CONFIG, "lanes_per_env must be a power of two in [4,64] and >= num_agents");
 
     const bool cte = (c.flags & MAPF_FLAG_SINGLE_AGENT) != 0;
+    // single-agent env: one staging row of H*W + 5N floats per env has to fit a wave's 64 KiB of LDS
+    auto cte_fits = [&](int l) { return (64 / l) * (c.height * c.width + 5 * c.num_agents) * 4 <= 56 * 1024; };
     if (cte && !c.lanes_per_env) {
-        // one staging row of H*W + 5N floats per env: widen the groups until a wave's rows fit 64 KiB of LDS
-        while (lpe < 64 && (64 / lpe) * (c.height * c.width + 5 * c.num_agents) * 4 > 56 * 1024) lpe <<= 1;
-        // the work of this env is the H*W observation row, which spreads over however many lanes the group has:
-        // widen until the launch has one two-wave workgroup per SIMD; half of that is enough once a group has 32 lanes
-        // (round 3, us per step single / fused: 8192 x 16x16 x 4 agents 5.0 / 2.5 at 8 lanes, 5.2 / 5.0 at 16;
-        // 1024 x 32x32 x 8 agents 5.2 / 2.65 at 16, 4.5 / 2.8 at 32, 4.7 / 3.3 at 64)
+        // The work of this env is the H*W observation row, which spreads over however many lanes the group has.
+        // Single-step launches: at most 32 cells per lane, then widen until the launch has one two-wave workgroup per
+        // SIMD (half of that once a group has 32 lanes).  Measured, us per step in phase (profiles/r04/
+        // cte_lanes_sweep.jsonl): 8192 x 16x16 x 4 agents 5.0 at 8 lanes, 5.2 at 16; 32x32 x 8 agents at 8 / 16 / 32 / 64
+        // lanes: 2048 envs 7.2 / 5.5 / 4.8 / 5.5, 4096 envs 8.2 / 6.9 / 6.2 / 9.0, 8192 envs 16.5 / 12.4 / 10.8 / 14.4,
+        // 16 384 envs 25.1 / 19.4 / 18.1 / 25.0.
+        while (lpe < 64 && c.height * c.width > 32 * lpe) lpe <<= 1;
+        while (lpe < 64 && !cte_fits(lpe)) lpe <<= 1;
         while (lpe < 64 && (int64_t)c.num_envs * lpe / 64 < (lpe >= 16 ? 512 : 1024)) lpe <<= 1;
     }
 #if defined(MAPF_DEV_C5)
@@ -825,6 +831,29 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
             e->sampler_blocks = sampler_blocks_for(B, 3);
             const int need = 3 * sampler_lds_bytes_per_wave(1, p.scratch_i16);
             if (e->wide_lds_bytes < need) e->wide_lds_bytes = need;
+        }
+    }
+    if (cte) {
+        // Fused launches keep the state in registers and write T rows per env: the fewer lanes per env, the fewer waves
+        // do the same stores, so they take the narrowest group that leaves 256 workgroups (same sweep, T = 100, us per
+        // step at 8 / 16 / 32 lanes: 2048 envs 2.5 / 2.9 / 2.8, 4096 envs 3.3 / 3.4 / 3.9, 8192 envs 8.4 / 8.6 / 8.9;
+        // 16x16 x 4 agents at 4 / 8 / 16 lanes: 8192 envs 2.26 / 2.45 / 3.17, 32 768 envs 6.8 / 8.2 / 13.0).
+        int lm = c.lanes_per_env ? c.lanes_per_env : pick_lpe(N);
+        if (!c.lanes_per_env) {
+            while (lm < 64 && !cte_fits(lm)) lm <<= 1;
+            while (lm < 64 && (int64_t)B * lm / 64 < 256) lm <<= 1;
+        }
+        const int Gm = 64 / lm;
+        auto &m = e->cte_many;
+        m.lpe = lm;
+        m.blocks = (B + Gm - 1) / Gm;
+        m.tab_off = ((Gm * (H + 2 * kRowPad) * 8) + 15) & ~15;
+        m.stage_off = m.tab_off + tab_bytes;
+        m.scratch_off = m.stage_off + (((Gm * (H * W + 5 * N) * 4) + 15) & ~15);
+        m.lds_bytes = m.scratch_off + (((Gm * scratch_i16_alloc * 2) + 15) & ~15);
+        if (m.lds_bytes > 64 * 1024) {
+            delete e;
+            return fail(nullptr, MAPF_ERR_CONFIG, "config needs more than 64 KiB of LDS per wavefront");
         }
     }
 
@@ -1342,7 +1371,7 @@ int mapf_step_many_sampled(mapf_handle e, int32_t T, const float *obs_in, uint64
                           info_agent, stream);
 }
 
-static CteIo make_cte_io(const mapf_engine *e) {
+static CteIo make_cte_io(const mapf_engine *e, bool fused = false) {
     CteIo io;
     memset(&io, 0, sizeof io);
     io.agents = e->d_agents;
@@ -1354,9 +1383,9 @@ static CteIo make_cte_io(const mapf_engine *e) {
     io.col_pad = e->col_pad;
     io.bn8 = e->bn8;
     io.steps_per_episode = e->p.steps_per_episode;
-    io.lds_tab_off = e->p.lds_tab_off;
-    io.lds_stage_off = e->p.lds_stage_off;
-    io.lds_scratch_off = e->p.lds_scratch_off;
+    io.lds_tab_off = fused ? e->cte_many.tab_off : e->p.lds_tab_off;
+    io.lds_stage_off = fused ? e->cte_many.stage_off : e->p.lds_stage_off;
+    io.lds_scratch_off = fused ? e->cte_many.scratch_off : e->p.lds_scratch_off;
     io.blocking_penalty = e->cte_blocking_penalty;
     io.move_after_goal_penalty = e->cte_move_after_goal_penalty;
     return io;
@@ -1364,11 +1393,13 @@ static CteIo make_cte_io(const mapf_engine *e) {
 
 static hipError_t launch_cte(const mapf_engine *e, const CteIo &io, bool step, hipStream_t s, CteMany many = CteMany{1, 2}) {
 #ifndef MAPF_NO_CTE_KERNELS
-    const LaunchPlan lp = plan_of(e);
+    LaunchPlan lp = plan_of(e);
+    const bool fused = step && many.T > 1;
+    if (fused) { lp.blocks = e->cte_many.blocks; lp.lds_bytes = e->cte_many.lds_bytes; }
 #define MAPF_CASE(L) \
     case L:          \
         return launch_cte_##L(lp, io, step, s, many);
-    switch (e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
+    switch (fused ? e->cte_many.lpe : e->lpe) { MAPF_FOR_LPE(MAPF_CASE) }
 #undef MAPF_CASE
 #endif
     return hipErrorInvalidValue;
@@ -1417,7 +1448,7 @@ int mapf_cte_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *o
     if (!actions || T < 1) return fail(e, MAPF_ERR_CONFIG, "null argument or T < 1");
     if (obs_mode < 0 || obs_mode > 2 || (obs_mode != 0 && !obs)) return fail(e, MAPF_ERR_CONFIG, "bad obs_mode / obs");
     if (!e->grids_set) return fail(e, MAPF_ERR_STATE, "mapf_set_grids must be called before mapf_cte_step_many");
-    CteIo io = make_cte_io(e);
+    CteIo io = make_cte_io(e, T > 1);
     io.actions = actions;
     io.obs = obs;
     io.reward = reward;
@@ -1644,6 +1675,15 @@ int mapf_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (lanes_per_env) *lanes_per_env = e->lpe;
     return e->special;  /* >= 0: id of the compile-time specialisation in use (0 = runtime-config kernel) */
+}
+
+int mapf_cte_many_launch_info(mapf_handle e, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env) {
+    if (!e || !e->cte) return fail(e, MAPF_ERR_STATE, "not a MAPF_FLAG_SINGLE_AGENT handle");
+    if (blocks) *blocks = e->cte_many.blocks;
+    if (threads) *threads = 128;
+    if (lds_bytes) *lds_bytes = e->cte_many.lds_bytes;
+    if (lanes_per_env) *lanes_per_env = e->cte_many.lpe;
+    return MAPF_OK;
 }
 
 }  // extern "C"

@@ -159,9 +159,11 @@ class VecSingleAgentReferenceModel:
         s = L.MapfState(counters=c.ctypes.data_as(C.c_void_p))
         self._check(self._lib.mapf_set_state(self._h, C.byref(s)), ValueError)
 
-    def launch_info(self) -> dict:
+    def launch_info(self, fused: bool = False) -> dict:
+        """Launch shape of ``step()`` (``fused=True``: of ``step_many()`` with T > 1, which picks its own group width)."""
         b, t, l, p = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-        self._lib.mapf_launch_info(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
+        fn = self._lib.mapf_cte_many_launch_info if fused else self._lib.mapf_launch_info
+        fn(self._h, C.byref(b), C.byref(t), C.byref(l), C.byref(p))
         return {"blocks": b.value, "threads": 128, "lds_bytes": l.value, "lanes_per_env": p.value, "specialized_kernel": 0,
                 "jit": False, "jit_note": "single-agent env"}
 

@@ -333,6 +333,9 @@ int mapf_jit_status(mapf_handle h, const char **why);
 /* dynamic-LDS bytes and grid size the step kernel is launched with (for DESIGN.md / profiling notes).
  * Returns >= 0: the id of the compile-time specialisation of the step kernel in use (0 = runtime-config kernel). */
 int mapf_launch_info(mapf_handle h, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env);
+/* the same for the fused launches of a MAPF_FLAG_SINGLE_AGENT handle (mapf_cte_step_many with T > 1), which pick their
+ * own group width; MAPF_ERR_STATE for other handles. */
+int mapf_cte_many_launch_info(mapf_handle h, int32_t *blocks, int32_t *threads, int32_t *lds_bytes, int32_t *lanes_per_env);
 
 #ifdef __cplusplus
 }

@@ -353,3 +353,47 @@ def test_wide_kernel_masked_step_leaves_masked_envs_untouched():
         for k in before:
             assert np.array_equal(before[k][b], after[k][b]), (k, b)
     assert (after["counters"][[0, 2, 3, 6], 0] == 1).all()
+
+
+# ---- single-agent env: episode ends at different steps, with and without the terminal observation ----------------------
+@pytest.mark.parametrize("lanes,B,H,W,N,spe", [(0, 130, 16, 16, 4, 7), (0, 40, 32, 32, 8, 5), (8, 65, 9, 7, 5, 3), (64, 24, 12, 12, 3, 1),
+                                                (16, 33, 10, 10, 12, 4)])
+@pytest.mark.parametrize("want_final", [False, True])
+def test_single_agent_env_staggered_resets_match_the_oracle(lanes, B, H, W, N, spe, want_final):
+    """Round 4 rebuilt this env's episode boundary: the placement draw is lane-parallel (first occurrences among 2N + 8
+    attempts made at once, SA-env:158-191), the reset observation is the observation wave's -- in ONE pass when nobody asks
+    for the terminal observation, in two when somebody does.  Episodes end in different steps (staggered phases, short
+    episodes, goal-seeking actions so that some end by success); generator words compared."""
+    from trace_util import CteEngineStepper, CteOracleStepper
+
+    cfg = {"env_name": "synthetic", "num_agents": N, "steps_per_episode": spe}
+    grids = synth_grids(B, H, W, 0.2, N, base_seed=150_000 + lanes)
+    seeds = list(range(B))
+    kw = {"lanes_per_env": lanes} if lanes else {}
+    eng = CteEngineStepper(grids, cfg, seeds=seeds, **kw)
+    orc = CteOracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset obs", eng.reset(), orc.reset())
+    counts = np.arange(B) % spe
+    eng.env.set_step_counts(counts)
+    for e, c in zip(orc.envs, counts):
+        e._step[0] = int(c)
+    rng = np.random.default_rng(9)
+    for t in range(50):
+        pos, gl = orc.positions().astype(int), orc.goals().astype(int)
+        d = gl - pos
+        greedy = np.where(np.abs(d[..., 0]) >= np.abs(d[..., 1]), np.where(d[..., 0] > 0, 3, np.where(d[..., 0] < 0, 1, 0)),
+                          np.where(d[..., 1] > 0, 2, 4))
+        acts = np.where(rng.random((B, N)) < 0.7, greedy, rng.integers(0, 5, size=(B, N))).astype(np.int8)
+        a = torch.as_tensor(acts, device=eng.env.device)
+        out = eng.env.step(a, auto_reset=True, want_final_obs=want_final)
+        ref = orc.step(acts)
+        for k in ("obs", "reward", "terminated", "truncated", "info"):
+            _eq(k, out[k].cpu().numpy(), ref[k], t)
+        done = (ref["terminated"] | ref["truncated"]).astype(bool)
+        if want_final and done.any():
+            _eq("final_obs", out["final_obs"].cpu().numpy()[done], ref["final_obs"][done], t)
+        if t % 7 == 0:
+            _eq("rng words", eng.rng_words(), orc.rng_words(), t)
+    _eq("positions", eng.positions(), orc.positions())
+    _eq("goals", eng.goals(), orc.goals())
+    eng.env.poll_error()

@@ -97,7 +97,11 @@ def test_cte_randomized_configuration_fuzz():
 
 
 @pytest.mark.parametrize("shape", [(130, 16, 16, 4, 23, 0), (65, 9, 7, 5, 6, 0), (40, 32, 32, 8, 31, 64), (24, 12, 12, 3, 1, 8),
-                                   (20, 40, 37, 40, 17, 0)])
+                                   (20, 40, 37, 40, 17, 0),
+                                   # fused and single-step launches of one handle on DIFFERENT group widths (lanes = 0: the
+                                   # engine picks 32 / 8 and 8 / 4 lanes at these batch sizes), and the narrow widths by hand
+                                   (2048, 32, 32, 8, 31, 0), (8192, 16, 16, 4, 23, 0), (130, 16, 16, 4, 23, 4), (70, 16, 16, 7, 9, 8),
+                                   (33, 20, 20, 16, 12, 16)])
 def test_cte_fused_launch_equals_single_steps_of_the_oracle(shape):
     """mapf_cte_step_many: T steps in one launch (positions in registers, the obstacle part of the observation row written
     once, the touched cells put back after every row) against the oracle stepped T times with reset-on-done; every
@@ -111,6 +115,8 @@ def test_cte_fused_launch_equals_single_steps_of_the_oracle(shape):
     a = CteEngineStepper(grids, cfg, seeds=seeds, lanes_per_env=lanes)
     b = CteOracleStepper(grids, cfg, seeds=seeds)
     _eq("reset obs", a.reset(), b.reset())
+    if lanes == 0 and B >= 2048:
+        assert a.env.launch_info()["lanes_per_env"] != a.env.launch_info(fused=True)["lanes_per_env"]
     rng = np.random.default_rng(4)
     for rep, (T, mode) in enumerate(((37, 2), (5, 1), (11, 0), (1, 2), (19, 2), (1, 0), (26, 1))):
         acts = rng.integers(0, 5, size=(T, B, N)).astype(np.int8)
