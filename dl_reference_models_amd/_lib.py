@@ -30,6 +30,8 @@ FLAG_LOCK_METRICS = 32
 FLAG_DETERMINISTIC = 64
 FLAG_SINGLE_AGENT = 256
 FLAG_TWO_WAVE_WIDE = 0x00800000
+FLAG_TABLE_WALK_OBS = 0x00400000
+FLAG_NO_BIT_ROWS = 0x00200000
 FLAG_SAMPLER_WORKGROUPS = 0x02000000
 FLAG_FORCE_SPARSE = 0x04000000
 FLAG_FORCE_DENSE = 0x08000000

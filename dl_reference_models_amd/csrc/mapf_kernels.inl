@@ -289,6 +289,8 @@ struct KRuntime {
     static constexpr bool kSamplerFront = false;
     static constexpr bool kSlicedDraw = false;
     static constexpr bool kMapAlways = false;
+    static constexpr int kL = 0, kV = 0;  // (observation length / window side when known at compile time)
+    static constexpr uint32_t kFlags = 0;
     __device__ static __forceinline__ int N(const Params &p) { return p.N; }
     __device__ static __forceinline__ int sr(const Params &p) { return p.sr; }
     __device__ static __forceinline__ int V(const Params &p) { return p.V; }
@@ -322,6 +324,8 @@ struct KFixed {
     // runtime-config kernel otherwise), so the all-pairs walk is not compiled in: at N = 64 its unrolled loops were
     // a third of the code (98 KB against a 64 KB instruction cache) and much of the register pressure
     static constexpr bool kMapAlways = N_ > 16;
+    static constexpr int kL = obs_len_of(SR_, FLAGS_), kV = 2 * SR_ + 1;
+    static constexpr uint32_t kFlags = FLAGS_;
     __device__ static __forceinline__ int N(const Params &) { return N_; }
     __device__ static __forceinline__ int sr(const Params &) { return SR_; }
     __device__ static __forceinline__ int V(const Params &) { return 2 * SR_ + 1; }
@@ -409,6 +413,8 @@ struct WMask<32> {
     __device__ __forceinline__ void clear_bit(int b) { lo &= ~(1u << b); }
     __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1u; }
     __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= w << shift; }
+    __device__ __forceinline__ void toggle_if(bool c, int b) { lo ^= c ? (1u << (b & 31)) : 0u; }
+    static __device__ __forceinline__ WMask pick(bool c, const WMask &x, const WMask &y) { return WMask{c ? x.lo : y.lo}; }
     __device__ __forceinline__ uint32_t nib(int t0) const { return (lo >> t0) & 15u; }
     __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
@@ -423,6 +429,8 @@ struct WMask<64> {
     __device__ __forceinline__ void clear_bit(int b) { lo &= ~(1ull << b); }
     __device__ __forceinline__ bool get(int b) const { return (lo >> b) & 1ull; }
     __device__ __forceinline__ void or_row(uint32_t w, int shift) { lo |= (uint64_t)w << shift; }
+    __device__ __forceinline__ void toggle_if(bool c, int b) { lo ^= c ? (1ull << (b & 63)) : 0ull; }
+    static __device__ __forceinline__ WMask pick(bool c, const WMask &x, const WMask &y) { return WMask{c ? x.lo : y.lo}; }
     __device__ __forceinline__ uint32_t nib(int t0) const { return (uint32_t)(lo >> t0) & 15u; }
     __device__ __forceinline__ WMask operator|(const WMask &o) const { return WMask{lo | o.lo}; }
     __device__ __forceinline__ WMask andnot(const WMask &o) const { return WMask{lo & ~o.lo}; }
@@ -448,6 +456,13 @@ struct WMask<128> {
         } else {
             hi |= (uint64_t)w << (shift - 64);
         }
+    }
+    __device__ __forceinline__ void toggle_if(bool c, int b) {
+        const uint64_t v = c ? 1ull : 0ull;
+        if (b < 64) lo ^= v << (b & 63); else hi ^= v << ((b - 64) & 63);
+    }
+    static __device__ __forceinline__ WMask pick(bool c, const WMask &x, const WMask &y) {
+        return WMask{c ? x.lo : y.lo, c ? x.hi : y.hi};
     }
     // t0 is a multiple of 4, so a nibble never straddles the two words
     __device__ __forceinline__ uint32_t nib(int t0) const {
@@ -1031,6 +1046,37 @@ __device__ __forceinline__ void emit_obs_planes(const Params &p, float *srow, co
     const int V = K::V(p), sr = K::sr(p), VV = V * V, ctr = sr * V + sr;
     const uint32_t flags = K::flags(p);
     constexpr uint32_t KS = 0x00204081u, MS = 0x01010101u;  // bit i of a nibble -> LSB of byte i
+    if constexpr (K::kFixed && K::kL % 4 == 0 && K::kV <= MAXV) {
+        // Rows of a multiple of four floats (L = 28, 52: the reference-default layouts) go to the staging buffer as 16-byte
+        // writes: with a row stride of L words, 32-bit writes of the same element by 64 lanes fall on 16 banks (gcd(L, 64) =
+        // 4: four lanes per bank, every write replayed four times), 16-byte writes of 16 lanes at a time cover all 64.
+        constexpr int L = K::kL, CV = K::kV * K::kV, CTR = (K::kV / 2) * K::kV + K::kV / 2;
+        float f[L];
+#pragma unroll
+        for (int t0 = 0; t0 < CV; t0 += 4) {
+            const uint32_t by = ((bit0.nib(t0) * KS) & MS) | (((bit1.nib(t0) * KS) & MS) << 1) | (((g4.nib(t0) * KS) & MS) << 2);
+            f[t0] = (float)(by & 0xFFu);
+            if (t0 + 1 < CV) f[t0 + 1] = (float)((by >> 8) & 0xFFu);
+            if (t0 + 2 < CV) f[t0 + 2] = (float)((by >> 16) & 0xFFu);
+            if (t0 + 3 < CV) f[t0 + 3] = (float)(by >> 24);
+        }
+        int q = CV;
+        f[q++] = gd_r;
+        f[q++] = gd_c;
+        if constexpr ((K::kFlags & MAPF_FLAG_GOAL_DISTANCE) != 0) f[q++] = fabsf(gd_r) + fabsf(gd_c);
+        if constexpr ((K::kFlags & MAPF_FLAG_BLOCKING_PRESSURE) != 0) f[q++] = pressure ? 1.0f : 0.0f;
+        if constexpr ((K::kFlags & MAPF_FLAG_ACTION_MASK) != 0) {
+            f[q++] = 1.0f;
+            f[q++] = (K::kV > 1 && !oa.get(CTR - K::kV)) ? 1.0f : 0.0f;
+            f[q++] = (K::kV > 1 && !oa.get(CTR + 1)) ? 1.0f : 0.0f;
+            f[q++] = (K::kV > 1 && !oa.get(CTR + K::kV)) ? 1.0f : 0.0f;
+            f[q++] = (K::kV > 1 && !oa.get(CTR - 1)) ? 1.0f : 0.0f;
+        }
+        float4 *dst = reinterpret_cast<float4 *>(srow);
+#pragma unroll
+        for (int i = 0; i < L; i += 4) dst[i >> 2] = make_float4(f[i], f[i + 1], f[i + 2], f[i + 3]);
+        return;
+    }
 #pragma unroll
     for (int t0 = 0; t0 < MAXV * MAXV; t0 += 4) {
         if (t0 < VV) {
@@ -3381,13 +3427,345 @@ __device__ __forceinline__ void obs3_wave(const Params &p, const Io &io, const L
     obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, G, true, gd_lut);
 }
 
+// ---- wave 1 of k_step3, prepared before B1 (round 4; grids of at most 64 - 2 kRowPad columns) ------------------------------
+// Before B1 the observation wave knows everything about its agent's observation except whether the move succeeds and who
+// else moved: the agent ends the step on its old cell or on its target.  While the state wave resolves the moves, this
+// wave builds for BOTH cells the obstacle / goal / occupancy windows -- from bit rows: the obstacle rows as loaded, and two
+// row sets of its own into which every agent ors its goal and its OLD cell -- plus its own goal's bit and the goal delta.
+// After B1 it picks one of the two, and what is left of the staggered view of MA-env:528 (agents <= i at their new cell,
+// agents > i at their old one) is a toggle of two window bits per successful mover of LOWER index anywhere near: every
+// move of the sequential loop takes an agent off a cell that held it and puts it on a cell that was empty at that moment,
+// so the occupancy after turn i is the initial occupancy XOR the toggles of the turns <= i.  Which lower-index agents can
+// matter at all (old cell within sr + 2 of mine: both of us move one cell at most) is a 16-bit mask made before B1 too;
+// the group's ballot of who moved cuts it down to a handful of table reads per wave.
+template <int MW>
+struct ObsCand {
+    WMask<MW> obst, gls, occ, own;
+    float gd_r, gd_c;
+};
+// LDS bit rows of k_step3 (grids with sentinel columns), behind the aux wave's staging and gd_lut (relative to
+// Io::lds_map_off): [goals | old cells | intents][G][H + 2 kRowPad], bit (column + col_pad) of row (row + kRowPad); cleared
+// and filled by the aux wave before B1
+// which instantiations of k_step3 hold the bit-row code at all (the host's choice, mapf_create, is the same): 16-lane
+// groups with windows up to 7 x 7.  (Groups of 4 and 8 lanes measured slower with the rows -- c3 5.63 against 5.42 us
+// staggered, c2 4.08 against 3.73: short table walks, cheap pair pass -- and merely compiling the paths in cost c3 4 %.)
+template <int LPE, int MW>
+constexpr bool k3_rows() { return LPE == 16 && MW <= 64; }
+__host__ __device__ constexpr int obs_rows_lds_off() { return 3072; }
+__host__ __device__ constexpr int obs_rows_lds_bytes(int G, int H) { return 3 * G * (H + 2 * kRowPad) * 8; }
+// the observation wave's half: what only needs the obstacle rows and the agent's own goal
+template <class K, int MW>
+__device__ __forceinline__ void obs_candidate_static(const Params &p, const Io &io, const uint64_t *obrows, const float *gd_lut,
+                                                     uint32_t cell, uint32_t goal, ObsCand<MW> &c) {
+    constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
+    const int V = K::V(p), sr = K::sr(p);
+    const int myr = (int)(cell >> 8), myc = (int)(cell & 255u);
+    const int r0 = myr - sr, c0 = myc - sr;
+    const int sh = c0 + io.col_pad;  // 0 .. 63 - V: the rows carry col_pad = kRowPad >= sr bits below column 0
+    const uint32_t vm = (1u << V) - 1u;
+    uint64_t ro[MAXV];
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) ro[d] = (d < V) ? obrows[r0 + d] : 0ull;
+    c.obst.clear(); c.own.clear();
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {
+        if (d < V) c.obst.or_row((uint32_t)(ro[d] >> sh) & vm, d * V);
+    }
+    window_set<MW>(c.own, goal, r0, c0, V);
+    const int gdr = (int)((goal >> 8) & 255u) - myr, gdc = (int)(goal & 255u) - myc;
+    c.gd_r = gd_lut[gdr + 63];
+    c.gd_c = gd_lut[128 + gdc + 63];
+}
+// the aux wave's half: everybody's goals and everybody's old cell in the window around `cell`
+template <class K, int MW>
+__device__ __forceinline__ void obs_candidate_rows(const Params &p, const Io &io, const uint64_t *goalb, const uint64_t *occO,
+                                                   uint32_t cell, WMask<MW> &gls, WMask<MW> &occ) {
+    constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
+    const int V = K::V(p), sr = K::sr(p);
+    const int r0 = (int)(cell >> 8) - sr, sh = (int)(cell & 255u) - sr + io.col_pad;
+    const uint32_t vm = (1u << V) - 1u;
+    uint64_t rg[MAXV], rq[MAXV];
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {  // (all reads of the window issue back to back)
+        rg[d] = (d < V) ? goalb[r0 + d] : 0ull;
+        rq[d] = (d < V) ? occO[r0 + d] : 0ull;
+    }
+    gls.clear(); occ.clear();
+#pragma unroll
+    for (int d = 0; d < MAXV; d++) {
+        if (d < V) {
+            gls.or_row((uint32_t)(rg[d] >> sh) & vm, d * V);
+            occ.or_row((uint32_t)(rq[d] >> sh) & vm, d * V);
+        }
+    }
+}
+// the two cells an agent can end the step on: its old cell, or the neighbour its action names when that is a free cell
+// of the grid (the pass bits of the hot plane, as state3_wave)
+__device__ __forceinline__ uint32_t step_target_or_old(uint32_t old, uint32_t pass, int act) {
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const bool want = act != 0 && ((pass >> ((act - 1) & 3)) & 1u) != 0;
+    return want ? (uint32_t)(((int)old + (dr << 8) + dc) & 0xFFFF) : old;
+}
+// ---- intent blocking (MA-env:608-623) from a bit row set ------------------------------------------------------------------
+// An agent that has reached its goal and did not move is "blocking" when some OTHER agent that has not reached its goal
+// (after this step's goal logic) intended to enter its cell.  Instead of exchanging every agent's intended cell inside the
+// group, the aux wave ors the intents into bit rows BEFORE B1 -- an agent publishes iff it has not reached its goal before
+// the step and does not stand on it afterwards, which is known ahead of the moves unless its old cell or its target IS its
+// goal -- and whoever needs the flag (state wave: per-agent outputs; aux wave: counters) reads one row behind B1 and adds,
+// by broadcast, the few agents whose publishing depended on the move.  (An agent that may be blocking has reached its goal
+// and publishes nothing itself, so its own intent never counts.)
+struct IntentOf {
+    uint32_t cell1;  // intended cell in the (+1, +1) encoding of AgentStep::intended1
+    int row, bit;    // its place in the rows (row index relative to row 0)
+    bool sure, unsure;
+};
+__device__ __forceinline__ IntentOf intent_of(const Io &io, uint32_t old, uint32_t goal, uint32_t flags0, uint32_t pass, int act) {
+    IntentOf t;
+    const int dr = (act == 1) ? -1 : ((act == 3) ? 1 : 0);
+    const int dc = (act == 2) ? 1 : ((act == 4) ? -1 : 0);
+    const int tr = (int)(old >> 8) + dr, tc = (int)(old & 255u) + dc;
+    t.cell1 = (uint32_t)(((tr + 1) << 8) | (tc + 1));
+    t.row = tr;
+    t.bit = tc + io.col_pad;  // >= col_pad - 1 >= 0
+    const bool want = act != 0 && ((pass >> ((act - 1) & 3)) & 1u) != 0;
+    const uint32_t tgt = want ? (uint32_t)((tr << 8) | tc) : old;
+    const bool unreached = (flags0 & kFlagReached) == 0;
+    t.unsure = unreached && (old == goal || tgt == goal);
+    t.sure = unreached && !t.unsure;
+    return t;
+}
+template <int LPE>
+__device__ __forceinline__ bool intent_blocks(const Io &io, const uint64_t *irow0, int lane, const IntentOf &t, uint32_t goal,
+                                              uint32_t cur) {
+    bool blocks = ((irow0[cur >> 8] >> ((cur & 255u) + io.col_pad)) & 1ull) != 0;
+    const bool late = t.unsure && cur != goal;  // publishes after all
+    uint64_t u = fold_groups<LPE>(__ballot(late));
+    const uint32_t mycell1 = cur + 0x0101u;
+    while (u) {  // (rare)
+        const int j = (int)__builtin_ctzll(u);
+        u &= u - 1;
+        blocks |= gshfl<LPE>(late ? t.cell1 : 0xFFFFFFFFu, j) == mycell1;
+    }
+    return blocks;
+}
+
+// An env that reaches its step limit in this step, is re-placed from its pre-drawn slot and has no taker for the terminal
+// observation shows its RESET observation instead (decide_end: subst) -- whatever the moves turn out to be.  Both preparing
+// waves see that coming from the same inputs and prepare that observation (everybody on its new start, the new goals)
+// in place of the two outcomes of the move.  (An env that ends by success before the limit is not foreseen: the
+// observation wave falls back to the table walk for it.)
+template <int LPE>
+__device__ __forceinline__ bool foresee_subst(const Io &io, int lane, int step_count_in, uint32_t nsg) {
+    const bool at_limit = step_count_in + 1 >= io.steps_per_episode && io.auto_reset && io.final_obs == nullptr;
+    return at_limit && gballot<LPE>(!slot_word_valid(nsg), lane) == 0;
+}
+// aux wave, before B1: the bit rows (cleared by this wave at entry) and its half of both candidates -> LDS
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void aux3_prepare_rows(const Params &p, const Io &io, uint64_t *brows, const int lane, const uint2 hot,
+                                                  const int act, const int step_count_in, const uint32_t nsg) {
+    constexpr int G = 64 / LPE;
+    const int grp = lane / LPE;
+    const int RS = io.H + 2 * kRowPad;
+    (void)p;
+    const bool fs = foresee_subst<LPE>(io, lane, step_count_in, nsg);
+    const uint32_t old = fs ? (nsg & 0xFFFFu) : (hot.x & 0xFFFFu), goal = fs ? (nsg >> 16) : (hot.x >> 16);
+    uint64_t *goalb = brows + grp * RS + kRowPad, *occO = brows + (G + grp) * RS + kRowPad;
+    atomicOr(reinterpret_cast<unsigned long long *>(&goalb[goal >> 8]), 1ull << ((goal & 255u) + io.col_pad));
+    atomicOr(reinterpret_cast<unsigned long long *>(&occO[old >> 8]), 1ull << ((old & 255u) + io.col_pad));
+    {   // intents of the step itself (never of the placement a foreseen reset shows)
+        const IntentOf t = intent_of(io, hot.x & 0xFFFFu, hot.x >> 16, (hot.y >> 16) & 0xFFu, hot.y >> 24, act);
+        uint64_t *irow0 = brows + (2 * G + grp) * RS + kRowPad;
+        if (t.sure) atomicOr(reinterpret_cast<unsigned long long *>(&irow0[t.row]), 1ull << t.bit);
+    }
+}
+// The per-agent outputs of a step -- rewards (MA-env:538-563, :668-690), {blocking, goal_reached_step}, done flags, the hot
+// plane incl. the image of an env re-placed from its slot -- by the STATE wave (round 4, with the intent bit rows): behind B1
+// it has nothing else to do, and the aux wave's chain (lock detector, info row, counters, history planes) is what the
+// launch ends with.  Same arithmetic as aux3_wave's block for workgroups without the rows.
+template <class K, int LPE>
+__device__ __forceinline__ void state3_outputs(const Params &p, const Io &io, const Lds &l, const uint64_t *irow0, const int lane,
+                                               const int env0, const int act, const uint2 hot, const uint32_t cur,
+                                               const EndDecision &dec, const uint32_t nsg) {
+    const int grp = lane / LPE, a = lane % LPE;
+    const int N = K::N(p);
+    const size_t idx0 = (size_t)env0 * N;
+    const uint64_t *myrows = l.rows + grp * (io.H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
+    Lane st;
+    st.pos = hot.x & 0xFFFFu;
+    st.goal = hot.x >> 16;
+    st.start = hot.y & 0xFFFFu;
+    st.flags = (hot.y >> 16) & 0xFFu;
+    const AgentStep as = agent_step(st, act, cur);
+    const IntentOf t = intent_of(io, st.pos, st.goal, st.flags, hot.y >> 24, act);
+    const bool blocks = intent_blocks<LPE>(io, irow0, lane, t, st.goal, cur);  // (every lane: it ballots and broadcasts)
+    const bool blocking = as.reached && !as.moved && blocks;
+    const bool done = dec.done;
+    const float term_reward = !done ? 0.0f : (!dec.trunc ? 1.0f : (dec.on_goal ? 0.0f : -1.0f));
+    const float reward = (as.grs ? 0.5f : 0.0f) + term_reward;
+    if (io.rewards) store_wt4(io.rewards + idx0, lane, __float_as_uint(reward));
+    if (io.info_agent)  // {blocking, goal_reached_step} as two bytes
+        store_wt2(reinterpret_cast<uchar2 *>(io.info_agent) + idx0, lane, (uint16_t)((blocking ? 1u : 0u) | (as.grs ? 0x100u : 0u)));
+    if (a == 0) {
+        if (io.terminated) (io.terminated + env0)[grp] = (uint8_t)dec.term;
+        if (io.truncated) (io.truncated + env0)[grp] = (uint8_t)dec.trunc;
+    }
+    Lane img;
+    img.pos = cur;
+    img.goal = st.goal;
+    img.start = st.start;
+    img.flags = (as.reached ? kFlagReached : 0) | (as.completed ? kFlagCompleted : 0) | (blocking ? kFlagPressure : 0);
+    if (__builtin_expect(__any(dec.fast_reset), 0)) {  // re-placed envs store the image reset() leaves (MA-env:440-455)
+        if (dec.fast_reset) {
+            img.start = nsg & 0xFFFFu;
+            img.goal = nsg >> 16;
+            img.pos = img.start;
+            img.flags = 0u;
+            (slots_of(io.scal, io.B) + idx0)[lane] = kSlotInvalid;  // consumed
+        }
+    }
+    // (an env that draws inline -- slow reset -- gets its hot plane below, after the draw)
+    if (!dec.slow_reset) store_lane_hot(io.agents + idx0, (size_t)lane, img, agent_pass_bits(myrows, img.pos, io.col_pad, io.W));
+}
+
+__device__ __forceinline__ void pin_mask(const WMask<32> &m) { asm volatile("" ::"v"(m.lo)); }
+__device__ __forceinline__ void pin_mask(const WMask<64> &m) { asm volatile("" ::"v"(m.lo)); }
+__device__ __forceinline__ void pin_mask(const WMask<128> &m) { asm volatile("" ::"v"(m.lo), "v"(m.hi)); }
+template <int MW>
+__device__ __forceinline__ void pin_cand(const ObsCand<MW> &c) {
+    pin_mask(c.obst); pin_mask(c.gls); pin_mask(c.occ); pin_mask(c.own);
+    asm volatile("" ::"v"(c.gd_r), "v"(c.gd_c));
+}
+template <int MW>
+__device__ __forceinline__ void window_toggle(WMask<MW> &m, bool on, uint32_t cell, int r0, int c0, int V) {
+    const int r = (int)((cell >> 8) & 255u) - r0, c = (int)(cell & 255u) - c0;
+    m.toggle_if(on && max((unsigned)r, (unsigned)c) < (unsigned)V, __mul24(r, V) + c);
+}
+template <class K, int LPE, int MW>
+__device__ __forceinline__ void obs3_wave_prepared(const Params &p, const Io &io, const Lds &l, uint64_t *brows, const int lane,
+                                                   const int env0, const uint2 hot, const int act, const uint32_t nsg,
+                                                   const int step_count_in, float *gd_lut) {
+    constexpr int G = 64 / LPE;
+    constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
+    using gm_t = typename GMask<LPE>::type;
+    const int grp = lane / LPE, a = lane % LPE;
+    const int N = K::N(p), H = io.H, V = K::V(p), sr = K::sr(p);
+    const int RS = H + 2 * kRowPad;
+    const uint32_t old = hot.x & 0xFFFFu, goal_real = hot.x >> 16;
+    const bool pressure_real = ((hot.y >> 16) & kFlagPressure) != 0;
+    const uint64_t *myrows = l.rows + grp * RS + kRowPad;
+    // ---- before B1 ----
+    const bool fs = foresee_subst<LPE>(io, lane, step_count_in, nsg);  // (the reset observation instead: see there)
+    uint32_t near = 0;  // lower-index agents of my env whose old cell lies within sr + 2 (rows and columns) of mine
+    {
+        uint32_t xo[LPE - 1];
+        group_xchg<LPE>(old, xo);
+        const int R = sr + 2;
+        const unsigned rlo = (old >> 8) - R, clo = (old & 255u) - R;
+#pragma unroll
+        for (int k = 1; k < LPE; k++) {
+            const unsigned tr = (xo[k - 1] >> 8) - rlo, tc = (xo[k - 1] & 255u) - clo;
+            near |= (max(tr, tc) <= 2u * R) ? (1u << (a ^ k)) : 0u;
+        }
+        near &= (1u << a) - 1u;
+    }
+    asm volatile("" ::"v"(near));  // (in a register BEFORE the barrier: left alone, the compiler sinks this to its first use)
+    MAPF_STAMP_W1(26);
+    wg_sync();  // B1: the moves
+    __builtin_amdgcn_s_setprio(3);  // (as obs3_wave; with the bit rows, obs / aux: 3 / 1 6.32 us staggered, 2 / 2 6.47, 3 / 2 6.52, 2 / 3 6.54, 1 / 3 6.63)
+    MAPF_STAMP_W1(11);
+    const uint4 ent = l.otab[lane];
+    const uint32_t cur = ent.y >> 16;
+    const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal_real, step_count_in + 1, nsg);
+    const uint32_t w = obs_flags_for(io, dec, pressure_real);
+    const bool any_fast_reset = __any(dec.fast_reset);
+    if (__builtin_expect(any_fast_reset, 0)) {  // the entries of re-placed groups, as obs3_wave leaves them (second pass / subst below)
+        uint4 mine = make_uint4(ent.x, ent.y, 0u, w);
+        const uint32_t rs = nsg, rs_pos = rs & 0xFFFFu;
+        if (dec.fast_reset) mine.z = rs;
+        if (dec.subst) mine = make_uint4(rs_pos | (rs_pos << 16), (rs >> 16) | (cur << 16), rs, w);
+        // (the loop below reads word x of LOWER-index entries of groups that are not substituted: unchanged for those)
+        if (dec.fast_reset) l.otab[lane] = mine;
+    }
+    const bool moved = cur != old;
+    const bool active = !dec.subst || fs;       // (a substitution that was not foreseen: the table walk below)
+    const bool staggered = !dec.subst;          // (the reset observation shows everybody where the placement puts them)
+    float *srow = l.stage + (size_t)(grp * N + a) * K::L(p);
+    {
+        ObsCand<MW> c;
+        const uint32_t cell = fs ? (nsg & 0xFFFFu) : cur, goal_shown = fs ? (nsg >> 16) : goal_real;
+        obs_candidate_static<K, MW>(p, io, myrows, gd_lut, cell, goal_shown, c);
+        obs_candidate_rows<K, MW>(p, io, brows + grp * RS + kRowPad, brows + (G + grp) * RS + kRowPad, cell, c.gls, c.occ);
+        const WMask<MW> obst = c.obst, own = c.own, gls = c.gls;
+        WMask<MW> occ = c.occ;
+        const float gd_r = c.gd_r, gd_c = c.gd_c;
+        const int r0 = (int)(cur >> 8) - sr, cc0 = (int)(cur & 255u) - sr;
+        const uint32_t M = (uint32_t)gballot_n<LPE>(moved, lane);
+        const uint4 *otabg = l.otab + grp * LPE;
+        uint32_t todo = staggered ? (near & M) : 0u;
+        while (__any(todo != 0u)) {
+            const bool on = todo != 0u;
+            const int j = on ? (int)__builtin_ctz(todo) : 0;
+            todo &= todo - 1u;
+            const uint32_t e = otabg[j].x;  // old | new << 16 of a lower-index agent that moved
+            window_toggle<MW>(occ, on, e & 0xFFFFu, r0, cc0, V);
+            window_toggle<MW>(occ, on, e >> 16, r0, cc0, V);
+        }
+        window_toggle<MW>(occ, moved && staggered, old, r0, cc0, V);  // the cell I left myself
+        MAPF_STAMP_W1(27);
+        if (active) {
+            occ.clear_bit(sr * V + sr);  // my own cell: "occ not in (UNASSIGNED, self)" MA-env:735
+            emit_obs_row<K, MW, MAXV>(p, srow, obst, occ, gls, own, gd_r, gd_c, pressure_real && staggered);
+        }
+    }
+    PairOut po;
+    if (__builtin_expect(__any(dec.subst && !fs), 0)) {
+        wave_lds_sync();
+        const uint4 e2 = l.otab[lane];
+        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, l.otab + grp * LPE, srow, dec.subst && !fs, a, e2.x >> 16, e2.y & 0xFFFFu, true,
+                                             false, 0, po, nullptr, gd_lut);
+    }
+    wave_lds_sync();
+    MAPF_STAMP_W1(12);
+    const bool any_slow = __any(dec.slow_reset);
+    const bool any_fast = __any(dec.fast_reset && !dec.subst);
+    if (!any_fast && !any_slow) {
+        if (io.obs) flush_obs_full<K, LPE>(p, io, io.obs, l.stage, lane, env0);
+    } else {
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, G, (int)((w >> kObsWSelShift) & 3u));
+    }
+    MAPF_STAMP_W1(13);
+    if (any_fast) {  // second pass, as obs_wave_step: the reset observation of groups whose terminal one just went to final_obs
+        const bool fr = dec.fast_reset && !dec.subst;
+        const uint32_t rpos = nsg & 0xFFFFu, rgoal = nsg >> 16;
+        uint4 *mine = l.otab + grp * LPE;
+        wave_lds_sync();
+        if (fr) mine[a] = make_uint4(rpos | (rpos << 16), rgoal, nsg, w);
+        wave_lds_sync();
+        observe<K, LPE, MW, kObsEmit, false>(p, io, myrows, mine, srow, fr, a, rpos, rgoal, true, false, 0, po, nullptr, gd_lut);
+        wave_lds_sync();
+        flush_obs<K, LPE>(p, io, l.stage, lane, env0, G, fr ? 0 : 2);
+    }
+    // The per-agent outputs (rewards, {blocking, goal_reached_step}, done flags, the hot plane), behind the stream: the aux
+    // wave's chain is what the launch ends with, and the state wave may have a slice of the background draw to run.  (Measured,
+    // us per step staggered / in phase: here 6.31 / 6.23; by the state wave right behind B1 6.47 / 6.16; by the state wave
+    // unless its env's slot says a slice may be due, else here: 6.58 / 6.11; round 3's kernel: 6.67 / 6.58.)
+    state3_outputs<K, LPE>(p, io, l, brows + (2 * G + grp) * RS + kRowPad, lane, env0, act, hot, cur, dec, nsg);
+#ifdef MAPF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MAPF_STAMP_W1(14);
+#endif
+    if (any_slow) wg_sync();  // B2
+}
+
 // ---- wave 2 of k_step3 -------------------------------------------------------------------------------------------
 // Everything of the step that follows the moves and is not the observation: goal / reward logic (MA-env:538-563), lock
 // flags and detector (:577-606), intent blocking (:608-623), info (:627-656), termination outputs (:668-690), the state
 // image (all four planes, counters) incl. the image of a re-placed env, episode statistics, the MAY_FINISH hint.
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const Lds &l, unsigned char *aux_lds, const int lane,
-                                          const int env0, const int act, const LaneRaw &raw, int *sc, const uint32_t nsg) {
+                                          const int env0, const int act, const LaneRaw &raw, int *sc, const uint32_t nsg,
+                                          uint64_t *brows) {
     constexpr int G = 64 / LPE;
     using gm_t = typename GMask<LPE>::type;
     const int grp = lane / LPE, a = lane % LPE;
@@ -3401,6 +3779,10 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
     const uint64_t *myrows = l.rows + grp * (io.H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
 
     MAPF_STAMP_W2(21);
+    if constexpr (k3_rows<LPE, MW>()) {
+        if (brows) aux3_prepare_rows<K, LPE, MW>(p, io, brows, lane, raw.h, act, sc[MAPF_CTR_STEP_COUNT], nsg);
+    }
+    MAPF_STAMP_W2(20);
     wg_sync();  // B1: the moves are published
     __builtin_amdgcn_s_setprio(1);  // (behind the observation wave: obs3_wave)
     MAPF_STAMP_W2(22);
@@ -3452,26 +3834,40 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
 
     // pair pass (MA-env:389-398 neighbour sets, :608-623 intent blocking) on DPP-exchanged words:
     // xa = new cell | reached << 16 | (distance delta + 256) << 17,  xz = intended cell (+1,+1) or ~0 once reached
-    uint32_t xa[LPE - 1], xz[LPE - 1];
+    uint32_t xa[LPE - 1];
     group_xchg<LPE>(cur | ((as.reached ? 1u : 0u) << 16) | ((uint32_t)(delta + 256) << 17), xa);
-    group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
     const uint32_t mycell1 = cur + 0x0101u;
     gm_t nbr = 0;
     int sum_biased = 0;
     bool blocks = false;
+    const bool rows = k3_rows<LPE, MW>() && brows != nullptr;
+    if (rows) {  // intents from the bit rows (intent_blocks); the state wave stores the per-agent outputs (state3_outputs)
 #pragma unroll
-    for (int k = 1; k < LPE; k++) {
-        const int d = cell_l1(xa[k - 1] & 0xFFFFu, cur);
-        const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);
-        nbr |= isn ? ((gm_t)1 << (a ^ k)) : 0;
-        sum_biased += isn ? (int)(xa[k - 1] >> 17) : 0;
-        blocks |= xz[k - 1] == mycell1;
+        for (int k = 1; k < LPE; k++) {
+            const int d = cell_l1(xa[k - 1] & 0xFFFFu, cur);
+            const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);
+            nbr |= isn ? ((gm_t)1 << (a ^ k)) : 0;
+            sum_biased += isn ? (int)(xa[k - 1] >> 17) : 0;
+        }
+        const IntentOf t = intent_of(io, st.pos, st.goal, st.flags, raw.h.y >> 24, act);
+        blocks = intent_blocks<LPE>(io, brows + (2 * G + grp) * (io.H + 2 * kRowPad) + kRowPad, lane, t, st.goal, cur);
+    } else {
+        uint32_t xz[LPE - 1];
+        group_xchg<LPE>(as.reached ? 0xFFFFFFFFu : as.intended1, xz);
+#pragma unroll
+        for (int k = 1; k < LPE; k++) {
+            const int d = cell_l1(xa[k - 1] & 0xFFFFu, cur);
+            const bool isn = (unsigned)(d - 1) < (unsigned)K::nearby(p);
+            nbr |= isn ? ((gm_t)1 << (a ^ k)) : 0;
+            sum_biased += isn ? (int)(xa[k - 1] >> 17) : 0;
+            blocks |= xz[k - 1] == mycell1;
+        }
     }
     const int sum_delta = delta + sum_biased - 256 * __popc((uint32_t)nbr);
     const bool blocking = as.reached && !as.moved && blocks;
 
     // ---- what does not need the lock detector leaves first: rewards, per-agent info, done flags, the hot plane ----
-    {
+    if (!rows) {
         const float term_reward = !done ? 0.0f : (!dec.trunc ? 1.0f : (dec.on_goal ? 0.0f : -1.0f));
         const float reward = (as.grs ? 0.5f : 0.0f) + term_reward;
         if (io.rewards) store_wt4(io.rewards + idx0, lane, __float_as_uint(reward));
@@ -3602,7 +3998,8 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
 // ---- wave 0 of k_step3 (FAST workgroups): the move phase, nothing else on its path -----------------------------------
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const Lds &l, const int lane, const int env0,
-                                            const int act, const uint2 hot, const int step_count_in, uint32_t nsg) {
+                                            const int act, const uint2 hot, const int step_count_in, uint32_t nsg,
+                                            const uint64_t *brows, DrawReq &dreq, int &d_stage) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE, a = lane % LPE;
     const int env = env0 + grp;
@@ -3629,6 +4026,16 @@ __device__ __forceinline__ void state3_wave(const Params &p, const Io &io, const
     MAPF_STAMP(19);
     // ---- an env of the wave ends its episode without a pre-drawn placement (rare): draw inline (reset_groups, B2 inside)
     const EndDecision dec = decide_end<LPE>(io, N, lane, cur, goal, step_count_in + 1, nsg);
+    // which slice of the background draw this wave runs in this launch (below, in the kernel); what it reads from memory is
+    // requested HERE, so that the round trip passes under the per-agent outputs
+    dreq.w0 = group_bcast<0, LPE>(nsg);
+    if constexpr (k3_rows<LPE, MW>()) {
+        d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
+        // (the observation wave stores the per-agent outputs when it runs its prepared path: obs3_wave_prepared)
+        const bool w1_outputs = (io.use_map & 6) == 2 && (io.obs || io.final_obs);
+        if (brows && !w1_outputs)
+            state3_outputs<K, LPE>(p, io, l, brows + (2 * G + grp) * (H + 2 * kRowPad) + kRowPad, lane, env0, act, hot, cur, dec, nsg);
+    }
     if (__builtin_expect(__any(dec.slow_reset), 0)) {
         const uint64_t *myrows = l.rows + grp * (H + 2 * kRowPad) + kRowPad;  // (the observation wave's; valid after B1)
         Lane st;
@@ -3693,6 +4100,8 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
                 gd_lut[128 + k] = goal_delta(k - 63, io.den_c, norm);
             }
         }
+        uint64_t *brows = reinterpret_cast<uint64_t *>(lds_raw + io.lds_map_off + obs_rows_lds_off());
+        const bool prepared = k3_rows<LPE, MW>() && (io.use_map & 6) == 2 && (io.obs || io.final_obs);  // (host: grids with sentinel columns)
         __builtin_amdgcn_sched_barrier(0);
         rows_commit<LPE>(io.grid_rows, io.H, l.rows, lane, env0, ngroups, rr);
         wave_lds_sync();
@@ -3703,6 +4112,12 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
             wg_sync();  // B0
             if (io.obs || io.final_obs) obs_wave_step<K, LPE, MW>(p, io, l, lane, env0, ngroups);
             return;
+        }
+        if constexpr (k3_rows<LPE, MW>()) {
+            if (prepared) {
+                obs3_wave_prepared<K, LPE, MW>(p, io, l, brows, lane, env0, hot1, act1, nsg1, step1, gd_lut);
+                return;
+            }
         }
         if (io.obs || io.final_obs)
             obs3_wave<K, LPE, MW>(p, io, l, lane, env0, hot1, nsg1, step1, gd_lut);
@@ -3736,6 +4151,19 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
     __builtin_amdgcn_sched_barrier(0);
     const Lds l = carve_lds(io, lds_raw);
     unsigned char *aux_lds = lds_raw + io.lds_map_off;  // (k_step3: 2 KiB for the aux wave's info / counter staging)
+    // prepared observation (obs3_wave_prepared): the aux wave owns the bit rows; they start a step empty (cleared under the
+    // latency of the loads above)
+    uint64_t *brows = nullptr;
+    if constexpr (k3_rows<LPE, MW>()) {
+        if ((io.use_map & 2) != 0) {
+            brows = reinterpret_cast<uint64_t *>(aux_lds + obs_rows_lds_off());
+            if (wv == 2) {
+                uint4 *z = reinterpret_cast<uint4 *>(brows);
+                const int n4 = obs_rows_lds_bytes(G, io.H) >> 4;
+                for (int k = lane; k < n4; k += 64) z[k] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
     bool is_agent = env_ok;  // (N == LPE)
     act = (full || is_agent) ? act : 0;
 #ifdef MAPF_STAMPS
@@ -3763,17 +4191,25 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
     }
     if (wv == 0) {
         MAPF_STAMP(1);
-        state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, raw.h, sc[0], nsg);
+#ifdef MAPF_STAMPS
+        {   // (stamps build: which XCD / CU / SIMD the state wave runs on, slot 3 of the workgroup's row)
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            if (p.dbg && lane == 0) p.dbg[(size_t)(env0 / G) * kDbgRow + 3] = (unsigned long long)hwid | ((unsigned long long)(xcc & 0xFu) << 32) | (1ull << 40);
+        }
+#endif
+        int d_stage = 0;
+        state3_wave<K, LPE, MW>(p, io, l, lane, env0, act, raw.h, sc[0], nsg, brows, dreq, d_stage);
         // The background draw of the next placement (draw_slice), one slice per launch, runs HERE: this wave has nothing
         // else to do once the moves are out.  (The window before B1, where round 2 ran it in the observation wave, closed
         // when B1 moved from 5.5 k to under 3 k cycles: run there by the aux wave -- inputs fetched with its first loads,
         // outputs at one 128-bit product each -- a slice still takes 1.7-2.6 k cycles of LDS staging and round trips and
         // holds B1 up for its workgroup: 6.25 us per staggered step against 5.6 here.)
         {
-            dreq.w0 = group_bcast<0, LPE>(nsg);
-            const int d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
+            if constexpr (!k3_rows<LPE, MW>()) d_stage = draw_request_body<K, LPE, false>(p, io, N, a, env, true, dreq);
             if (__builtin_expect(__any(d_stage != 0), 0)) {
-                __builtin_amdgcn_s_setprio(0);  // (background work: behind everything that a step waits for)
+                __builtin_amdgcn_s_setprio(0);  // (background work: behind everything that a step waits for; 1 or 2: -0.3 %)
                 MAPF_STAMP(4);
                 draw_slice<K, LPE>(p, io, l.scratch, lane, env, d_stage, dreq);
 #ifdef MAPF_STAMPS
@@ -3792,7 +4228,7 @@ __global__ __launch_bounds__(192, (WPS ? WPS : 1)) void k_step3(const Params *__
         return;
     }
     // ---- aux wave ----
-    aux3_wave<K, LPE, MW>(p, io, l, aux_lds, lane, env0, act, raw, sc, nsg);
+    aux3_wave<K, LPE, MW>(p, io, l, aux_lds, lane, env0, act, raw, sc, nsg, brows);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

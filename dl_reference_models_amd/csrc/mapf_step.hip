@@ -65,6 +65,7 @@ struct mapf_engine {
     int special = 0;  // id in MAPF_SPECIALIZATIONS, 0 = runtime-config kernel
     int dense = 0;    // the step grid has more than three waves per SIMD: the 128-register build of k_step (WPS = 4)
     int many_dense = 0;  // the fused launch has more than two waves per SIMD: the 128-register build of k_step_many
+    int obs_prepared = 0;  // k_step3 with bit rows (goals / old cells / intents: obs3_wave_prepared, state3_outputs; Io::use_map bit 1)
     int three_wave = 0;  // k_step3 (state / observation / aux wave): specialised finite shapes with N = 4 or 8, not dense
     int rt_sliced = 0;   // runtime-config kernels with the sliced background draw (KRuntimeSliced): full groups of 4 / 8 agents
     int wide3 = 0;       // k_stepw: 64-lane groups with the cell-map conditions met step on the three-wave kernel with bit rows
@@ -149,7 +150,8 @@ struct DeviceScope {
     } while (0)
 
 // engine knobs of mapf_config.flags that choose among builds of the same kernel (never part of the env's configuration)
-constexpr uint32_t kKernelChoiceFlags = MAPF_FLAG_FORCE_DENSE | MAPF_FLAG_FORCE_SPARSE | MAPF_FLAG_SAMPLER_WORKGROUPS | MAPF_FLAG_TWO_WAVE_WIDE;
+constexpr uint32_t kKernelChoiceFlags = MAPF_FLAG_FORCE_DENSE | MAPF_FLAG_FORCE_SPARSE | MAPF_FLAG_SAMPLER_WORKGROUPS | MAPF_FLAG_TWO_WAVE_WIDE |
+                                        MAPF_FLAG_TABLE_WALK_OBS | MAPF_FLAG_NO_BIT_ROWS;
 
 // Development builds only (-DMAPF_DEV): knobs read from the environment for A/B timing.  The shipped library reads
 // MAPF_JIT_CACHE_DIR (and the usual XDG / HOME variables behind it) and nothing else: which kernel a handle runs is a
@@ -811,6 +813,13 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
                           // difference between fitting the CU's 160 KiB of LDS and a second round of workgroups)
         e->lds_map_off = e->lds_bytes;
         e->lds_bytes += 3072;  // + 1 KiB: the observation wave's goal-delta table (obs3_wave)
+        // grids whose rows carry sentinel columns: the bit rows of the prepared observation (obs3_wave_prepared)
+        // (16-lane groups, windows up to 7 x 7.  Groups of 4 and 8 lanes: measured slower with the rows -- c3 5.63 against
+        //  5.42 us staggered, c2 4.08 against 3.73 -- their table walks are short and the aux wave's pair pass is cheap)
+        if (e->col_pad && e->mask_w <= 64 && lpe == 16 && !(c.flags & MAPF_FLAG_NO_BIT_ROWS)) {
+            e->obs_prepared = 1;
+            e->lds_bytes += obs_rows_lds_bytes(G, H);
+        }
     }
     if (finite_sampled) {  // the sampler workgroups of a k_step launch have their own LDS layout
         const int need = (step_threads(lpe) / 64) * sampler_lds_bytes_per_wave(G, p.scratch_i16);
@@ -1251,7 +1260,8 @@ static int step_impl(mapf_handle e, const int8_t *actions, const uint8_t *env_ma
     io.W = e->p.W;
     io.col_pad = e->col_pad;
     io.bn8 = e->bn8;
-    io.use_map = e->use_map;
+    // (bits 1, 2: small groups only, where bit 0 is never looked at: bit rows in use; observation wave walks the table all the same)
+    io.use_map = e->use_map | (e->obs_prepared << 1) | ((e->cfg.flags & MAPF_FLAG_TABLE_WALK_OBS) ? 4 : 0);
     io.lds_map_off = e->lds_map_off;
     io.eps_floor = e->p.eps_floor;
     io.steps_per_episode = e->p.steps_per_episode;

@@ -113,6 +113,10 @@ def config_flags(cfg: dict) -> int:
         f |= L.FLAG_SAMPLER_WORKGROUPS
     if cfg.get("wide_kernel") == "two_wave":  # engine knob: 64-lane groups on the two-wave kernel with the LDS cell map
         f |= L.FLAG_TWO_WAVE_WIDE
+    if cfg.get("small_group_observation") == "table_walk":  # engine knob: round 3's observation wave (A/B, tests)
+        f |= L.FLAG_TABLE_WALK_OBS
+    if cfg.get("small_group_rows") == "off":  # engine knob: round 3's three-wave kernel (no bit rows at all)
+        f |= L.FLAG_NO_BIT_ROWS
     return f
 
 

@@ -78,6 +78,11 @@ extern "C" {
                                              * sampler workgroups of the step grid instead of slices inside the env workgroups */
 #define MAPF_FLAG_TWO_WAVE_WIDE 0x00800000u /* engine knob (tests / A-B): 64-lane groups step on the two-wave kernel with the
                                              * word-per-cell LDS map (rounds 1-3) instead of the three-wave kernel with bit rows */
+#define MAPF_FLAG_TABLE_WALK_OBS 0x00400000u /* engine knob (tests / A-B): the observation wave of the three-wave small-group
+                                             * kernel walks the agent table after the moves (round 3) instead of preparing
+                                             * both outcomes of its agent's move from bit rows before them (round 4) */
+#define MAPF_FLAG_NO_BIT_ROWS 0x00200000u /* engine knob (tests / A-B): the three-wave small-group kernel as of round 3 -- no
+                                           * goal / occupancy / intent bit rows, per-agent outputs by the aux wave */
 #define MAPF_FLAG_SEQUENTIAL_RESET 0x20000000u /* engine knob (tests): in-kernel resets always take the sequential
                                                  * sampler (otherwise only after a Lemire rejection or when F = 2N) */
 #define MAPF_FLAG_NO_CELL_MAP 0x40000000u   /* engine knob (tests / A-B): never use the LDS cell-map path of wide groups */

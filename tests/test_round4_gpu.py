@@ -355,6 +355,116 @@ def test_wide_kernel_masked_step_leaves_masked_envs_untouched():
     assert (after["counters"][[0, 2, 3, 6], 0] == 1).all()
 
 
+# ---- k_step3 with bit rows: 16-lane groups (the reference's training setup and its runtime-config siblings) -----------
+_KNOBS16 = {None: {}, "table_walk": {"small_group_observation": "table_walk"}, "rows_off": {"small_group_rows": "off"}}
+
+
+@pytest.mark.parametrize("knob", list(_KNOBS16))
+@pytest.mark.parametrize("H,W,over", [
+    (32, 32, {"sensor_range": 3, "include_action_mask_in_obs": False}),                      # specialisation 6 (main.py:55-68)
+    (20, 21, {"sensor_range": 2, "steps_per_episode": 6}),                                    # runtime-config kernel, 5 x 5 windows, action mask
+    (12, 54, {"sensor_range": 3, "include_goal_distance": True, "include_action_mask_in_obs": False}),  # widest grid with sentinel columns
+    (12, 56, {"sensor_range": 3, "include_action_mask_in_obs": False}),                      # no sentinel columns: no rows whatever the knob
+    (16, 16, {"sensor_range": 4, "steps_per_episode": 5}),                                    # 9 x 9 windows: no rows
+    (4, 40, {"sensor_range": 1, "steps_per_episode": 4, "include_action_mask_in_obs": False}),  # a corridor: contended moves, intents onto goals
+])
+def test_sixteen_lane_groups_with_and_without_bit_rows_match_the_oracle(H, W, over, knob):
+    """Groups of 16 agents on the three-wave kernel: observation wave from the bit rows (goals / old cells, toggles of the
+    lower-index movers nearby), intent blocking from the intent rows, per-agent outputs by the observation wave (round 4) --
+    and, by the engine knobs, round 3's table walk / round 3's kernel.  All against the oracle: staggered episode ends
+    (foreseen reset observations), with and without the terminal observation, a ragged last workgroup."""
+    n, B = 16, 22
+    cfg = {"env_name": "synthetic", "num_agents": n, "include_action_mask_in_obs": True, "steps_per_episode": 9}
+    cfg.update(over)
+    grids = synth_grids(B, H, W, 0.1, n, base_seed=96_000)
+    seeds = list(range(70, 70 + B))
+    for want_final in (False, True):
+        eng = EngineStepper(grids, cfg, seeds=seeds, want_final_obs=want_final, **_KNOBS16[knob])
+        orc = OracleStepper(grids, cfg, seeds=seeds)
+        assert eng.env.launch_info()["threads"] == 192
+        _eq("reset", eng.reset(), orc.reset())
+        counts = np.arange(B) % int(cfg["steps_per_episode"])
+        eng.set_step_counts(counts)
+        orc.set_step_counts(counts)
+        rng = np.random.default_rng(12)
+        for t in range(60):
+            a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+            if t % 3 == 2:  # more agents pushing the same way: blocked moves, intents into occupied cells
+                a[:, ::2] = 2 + 2 * (t % 2)
+            ra, rb = eng.step(a), orc.step(a)
+            for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+                _eq(k, ra[k], rb[k], t)
+            done = (rb["terminated"] | rb["truncated"]).astype(bool)
+            if want_final and done.any():
+                _eq("final_obs", ra["final_obs"][done], rb["final_obs"][done], t)
+        _eq("positions", eng.positions(), orc.positions())
+        _eq("goals", eng.goals(), orc.goals())
+        _eq("rng words", eng.rng_words(), orc.rng_words())
+        eng.env.poll_error()
+
+
+def test_sixteen_lane_groups_unreached_agent_standing_on_its_goal():
+    """The case the intent rows cannot decide before the moves: an agent that has not "reached" its goal but stands on it
+    (an injected state), or whose target is its goal -- it publishes its intent iff it does not end the step there."""
+    n, B = 16, 8
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 3, "include_action_mask_in_obs": False, "steps_per_episode": 50}
+    grids = synth_grids(B, 10, 10, 0.05, n, base_seed=97_000)
+    seeds = list(range(B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        if t % 8 == 3:  # move every agent's goal under its feet (flags untouched: reached stays as it is)
+            pos = eng.positions()
+            eng.env.set_state(goals=pos.copy())
+            for b in range(B):
+                orc.batch.envs[b].goals[:] = pos[b]
+                orc.batch.envs[b].rebuild_owner_maps()
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            _eq(k, ra[k], rb[k], t)
+    eng.env.poll_error()
+
+
+def test_sixteen_lane_groups_invalid_action_and_masked_step():
+    """A workgroup with an invalid action or a step mask runs the two-wave code of the kernel (no rows): same results."""
+    n, B = 16, 9
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 3, "include_action_mask_in_obs": False, "steps_per_episode": 30}
+    grids = synth_grids(B, 14, 15, 0.1, n, base_seed=98_000)
+    seeds = list(range(B))
+    eng, orc = EngineStepper(grids, cfg, seeds=seeds), OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    rng = np.random.default_rng(2)
+    for t in range(5):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        _eq("obs", ra["obs"], rb["obs"], t)
+    a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+    a[2, 9] = 7
+    eng.step(a)
+    with pytest.raises(ValueError, match="Invalid action 7 for agent_9"):
+        eng.env.poll_error()
+    for b in range(B):
+        rc, *_ = orc.batch.envs[b].step(a[b].astype(np.int32))
+        assert rc == (orc.orc.ERR_BAD_ACTION if b == 2 else 0)
+    _eq("positions", eng.positions(), orc.positions())
+    for t in range(5):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "info_all", "info_agent"):
+            _eq(k, ra[k], rb[k], t)
+    before = eng.env.get_state()
+    mask = torch.tensor([1, 0, 1, 1, 0, 0, 1, 1, 0], dtype=torch.uint8, device=eng.env.device)
+    at = torch.from_numpy(rng.integers(0, 5, size=(B, n)).astype(np.int8)).to(eng.env.device)
+    eng.env.step(at, env_mask=mask)
+    eng.env.poll_error()
+    after = eng.env.get_state()
+    for b in (1, 4, 5, 8):
+        for k in before:
+            assert np.array_equal(before[k][b], after[k][b]), (k, b)
+
+
 # ---- single-agent env: episode ends at different steps, with and without the terminal observation ----------------------
 @pytest.mark.parametrize("lanes,B,H,W,N,spe", [(0, 130, 16, 16, 4, 7), (0, 40, 32, 32, 8, 5), (8, 65, 9, 7, 5, 3), (64, 24, 12, 12, 3, 1),
                                                 (16, 33, 10, 10, 12, 4)])

@@ -5,7 +5,9 @@ round -- differences of a percent that tools/ab2.sh (one process per build) lose
 listed twice differs by up to 0.7 % between its two engines -- where their buffers landed in memory -- so read
 differences below one percent as "none".)
 AB_WORKLOAD=<name> selects another workload of workloads.py (default: the headline); AB_GENERIC=1 the runtime-config kernels.
-Usage on the GPU box: python3 tools/ab_inproc.py [--staggered] [--rounds 30] lib_a.so lib_b.so ..."""
+A build may be followed by engine knobs of the env config, `lib.so@key=value,key=value` (e.g. lib.so@small_group_observation=
+table_walk): the same library, another kernel choice.
+Usage on the GPU box: python3 tools/ab_inproc.py [--staggered] [--rounds 30] lib_a.so lib_b.so[@knob=value] ..."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,17 +18,21 @@ from dl_reference_models_amd import workloads as wl
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 stag = "--staggered" in sys.argv
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 30
-libs = [a for a in args if a.endswith(".so")]
+libs = [a for a in args if a.split("@")[0].endswith(".so")]
 name = os.environ.get("AB_WORKLOAD", wl.HEADLINE)
 b = wl.WORKLOADS[name][0]
 engines = []
-for path in libs:
+for spec in libs:
+    path, _, knobs = spec.partition("@")
     os.environ["MAPF_LIB"] = os.path.abspath(path)
     import importlib
     from dl_reference_models_amd import _lib, vec_env
     cfg = wl.workload_config(name, list(range(b)))
     if os.environ.get("AB_GENERIC"):  # the runtime-config kernels on the same shape
         cfg["force_generic_kernel"] = True
+    for kv in filter(None, knobs.split(",")):
+        k, _, v = kv.partition("=")
+        cfg[k] = v
     env = vec_env.VecReferenceModel(cfg)
     env.reset()
     n, spe = cfg["num_agents"], int(cfg["steps_per_episode"])
@@ -44,7 +50,7 @@ for path in libs:
         cp = torch.cuda.current_stream().cuda_stream
         for t in range(100): env.step_raw(base + t * stride, cp, 1)
     g.replay(); torch.cuda.synchronize()
-    engines.append((path, env, g, acts))
+    engines.append((spec, env, g, acts))
 res = {p: [] for p in libs}
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for r in range(rounds):

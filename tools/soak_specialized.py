@@ -7,7 +7,7 @@ also end by success at arbitrary steps), with and without the terminal observati
 positions, goals and generator words every few steps.  tests/test_soak_gpu.py runs a short one (run_soak below); the
 long ones are recorded in DESIGN.md section 2.
 Usage: python tools/soak_specialized.py [master_seed] [cases]
-Environment: SOAK_GENERIC=1 (the runtime-config kernels on the same shapes), SOAK_DENSE=1 (the 128-register builds), SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_SEQ=1 (sequential
+Environment: SOAK_GENERIC=1 (the runtime-config kernels on the same shapes), SOAK_DENSE=1 (the 128-register builds), SOAK_N=4|8|16 (one agent count only; 16 = specialisation 6, sensor_range 3), SOAK_FINAL=0|1 (terminal observation off / on), SOAK_KNOBS=key=value,... (engine knobs of the env config for every handle), SOAK_SEQ=1 (sequential
 reset, the A/B), SOAK_ONLY=<case> (run one case of the sequence), SOAK_WATCH=<case>:<env> (print that env's placement slot
 and staging buffer before every step).  Cases are NOT independent on the GPU side: what a kernel finds in LDS depends on
 the launches before it, so a failure is reported with its case number in the sequence."""
@@ -116,7 +116,8 @@ if __name__ == "__main__":
     err = run_soak(int(sys.argv[1]) if len(sys.argv) > 1 else 2026, int(sys.argv[2]) if len(sys.argv) > 2 else 200,
                    only_n=int(env["SOAK_N"]) if env.get("SOAK_N") else None,
                    final=(env["SOAK_FINAL"] == "1") if env.get("SOAK_FINAL") else None, sequential=bool(env.get("SOAK_SEQ")),
-                   only=int(env.get("SOAK_ONLY", "-1")), watch=w, log=lambda m: print(m, flush=True))
+                   only=int(env.get("SOAK_ONLY", "-1")), watch=w, log=lambda m: print(m, flush=True),
+                   knobs=dict(kv.split("=", 1) for kv in filter(None, env.get("SOAK_KNOBS", "").split(","))) or None)
     if err:
         print(err, flush=True)
         sys.exit(1)

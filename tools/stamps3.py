@@ -2,7 +2,7 @@
 """Diagnostic: timeline of the three-wave step kernel (k_step3) from in-kernel s_memtime stamps, in cycles after the
 state wave's entry (median / p95 over workgroups and launches, and for the slowest workgroup of each launch).
 
-Needs a -DMAPF_STAMPS library (never the shipped one): MAPF_STAMPS_LIB=<path> python tools/stamps3.py [--stagger]
+Needs a -DMAPF_STAMPS library (never the shipped one): MAPF_STAMPS_LIB=<path> [STAMPS_KNOBS=key=value,...] python tools/stamps3.py [workload] [--stagger]
 """
 import ctypes as C, os, sys
 import numpy as np
@@ -17,6 +17,8 @@ stagger = "--stagger" in sys.argv
 name = args[0] if args else wl.HEADLINE
 b = wl.WORKLOADS[name][0]
 cfg = wl.workload_config(name, list(range(b)))
+for kv in filter(None, os.environ.get("STAMPS_KNOBS", "").split(",")):  # engine knobs of the env config: key=value,key=value
+    cfg[kv.partition("=")[0]] = kv.partition("=")[2]
 env = VecReferenceModel(cfg)
 env.reset()
 if stagger:
@@ -43,9 +45,9 @@ names = {4: "W0 first 16 B of records + actions", 5: "W0 whole records", 0: "W0 
          17: "W0 rewards / flags issued", 18: "W0 records issued", 8: "W0 body done", 9: "W0 stores drained",
          10: "W1 rows in LDS", 11: "W1 past B1", 12: "W1 observation staged", 13: "W1 stream issued", 14: "W1 stream drained",
          6: "W1 wave entry", 7: "W2 wave entry",
-         25: "W1 window rows in registers", 26: "W1 window masks built", 27: "W1 turn-dependent cells resolved",
-         21: "W2 state in registers", 22: "W2 past B1", 24: "W2 rewards / flags / hot plane issued", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
-order = [0, 16, 2, 19, 8, 9, 6, 10, 11, 25, 26, 27, 12, 13, 14, 7, 21, 22, 24, 29, 30, 31]
+         25: "W1 window rows in registers / k_step3: first candidate prepared", 26: "W1 window masks built / k_step3: arrives at B1", 27: "W1 turn-dependent cells resolved",
+         21: "W2 state in registers", 20: "W2 arrives at B1", 22: "W2 past B1", 24: "W2 rewards / flags / hot plane issued", 29: "W2 lock detector done", 30: "W2 info / counters stored", 31: "W2 end (slice incl.)"}
+order = [0, 16, 2, 19, 8, 9, 6, 10, 25, 26, 11, 27, 12, 13, 14, 7, 21, 20, 22, 24, 29, 30, 31]
 print(f"workload {name} ({'staggered' if stagger else 'synchronised'}): {blocks} workgroups x {info['threads']} threads; cycles after the state wave's entry")
 end = np.max(np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]]), axis=0)
 slow = end.argmax(axis=1)
@@ -56,6 +58,29 @@ for k in order:
     sl = np.array([rel[t, slow[t], k] for t in range(rel.shape[0])])
     print(f"  {names[k]:34s} median {np.median(v):7.0f}  p95 {np.percentile(v, 95):7.0f}   slowest workgroup {np.median(sl):7.0f}")
 print(f"  workgroup end (last of the three)  median {np.median(end):7.0f}  p95 {np.percentile(end, 95):7.0f}   slowest workgroup {np.median(end.max(axis=1)):7.0f}")
+three = np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]])
+who = three.argmax(axis=0)
+print(f"  workgroup end: p99 {np.percentile(end, 99):.0f}  p99.9 {np.percentile(end, 99.9):.0f}; last wave of a workgroup: state {np.mean(who == 0):.2f} / obs {np.mean(who == 1):.2f} / aux {np.mean(who == 2):.2f}; "
+      f"of the slowest 1 %: state {np.mean(who[end >= np.percentile(end, 99)] == 0):.2f} / obs {np.mean(who[end >= np.percentile(end, 99)] == 1):.2f} / aux {np.mean(who[end >= np.percentile(end, 99)] == 2):.2f}")
+# the launch as a whole: when the workgroups enter (dispatch ramp) and when the last one ends, after the first entry
+ent = full[:, :, 15]
+last = np.max(np.stack([full[:, :, 9], full[:, :, 14], full[:, :, 31]]), axis=0)
+# (s_memtime counters differ between XCDs: entries are taken relative to the first entry on the same XCD -- slot 3 holds the
+#  state wave's HW_REG_XCC_ID in bits 32-35; k_step without it: workgroup b is assumed to run on XCD b mod 8)
+hw3 = full[-1, :, 3]
+xcd = ((hw3 >> 32) & 0xF) if (hw3 >> 40).any() or full[:, :, 4].any() and False else (np.arange(ent.shape[1]) % 8)
+if (hw3 >> 32).any():
+    xcd = (hw3 >> 32) & 0xF
+t0 = np.zeros_like(ent)
+for x in np.unique(xcd):
+    m = xcd == x
+    t0[:, m] = np.where(ent[:, m] > 0, ent[:, m], np.iinfo(np.int64).max).min(axis=1, keepdims=True)
+ok = ent > 0
+rel_e, rel_l = np.where(ok, ent - t0, 0), np.where(ok, last - t0, 0)
+print(f"  launch: workgroup entries spread over {np.median(rel_e.max(axis=1)):.0f} cycles (median entry {np.median(rel_e[ok]):.0f}, p95 {np.percentile(rel_e[ok], 95):.0f}); "
+      f"last workgroup ends {np.median(rel_l.max(axis=1)):.0f} cycles after the first entry on its XCD (median workgroup {np.median(rel_l[ok]):.0f}, p95 {np.percentile(rel_l[ok], 95):.0f})")
+late = (ent - t0) > np.percentile(ent - t0, 90, axis=1, keepdims=True)
+print(f"  the 10 % of workgroups that enter last: duration median {np.median((last - ent)[late]):.0f}  (all: {np.median(last - ent):.0f})")
 kind = full[:, :, 23]
 if (kind > 0).any():
     print(f"  state waves running a draw slice (after B1) per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
@@ -75,7 +100,7 @@ if samp.shape[1]:  # sampler workgroups (their own clock origin: only durations 
         d12 = (samp[:, :, 2] - samp[:, :, 1])[act]
         print(f"  active sampler wave (wave 0 of its workgroup): draw {np.median(d12):.0f} (p95 {np.percentile(d12, 95):.0f}), entry -> stored median {np.median(d03):.0f}  p95 {np.percentile(d03, 95):.0f}  max {d03.max():.0f}")
 
-if full[:, :, 3].any():  # k_stepw stamps build: HW_REG_HW_ID of the three waves (gfx9: simd_id bits 5:4, cu_id 11:8, sh 12, se 15:13; xcc in the high bits)
+if info["lanes_per_env"] == 64 and full[:, :, 3].any():  # k_stepw stamps build: HW_REG_HW_ID of the three waves (gfx9: simd_id bits 5:4, cu_id 11:8, sh 12, se 15:13; xcc in the high bits)
     hw = full[-1, :, 3:6]
     simd = (hw >> 4) & 3
     cu = ((hw >> 8) & 0xFF) | ((hw >> 32) << 8)  # cu_id, sh_id, se_id of HW_ID and the XCC id: one value per CU
