@@ -3749,7 +3749,8 @@ __device__ __forceinline__ void obs3_wave_prepared(const Params &p, const Io &io
     // The per-agent outputs (rewards, {blocking, goal_reached_step}, done flags, the hot plane), behind the stream: the aux
     // wave's chain is what the launch ends with, and the state wave may have a slice of the background draw to run.  (Measured,
     // us per step staggered / in phase: here 6.31 / 6.23; by the state wave right behind B1 6.47 / 6.16; by the state wave
-    // unless its env's slot says a slice may be due, else here: 6.58 / 6.11; round 3's kernel: 6.67 / 6.58.)
+    // unless its env's slot says a slice may be due, else here: 6.58 / 6.11; by the state wave unless an env of the workgroup
+    // is re-placed in this step, else here: 6.41 / 6.09; round 3's kernel: 6.67 / 6.58.)
     state3_outputs<K, LPE>(p, io, l, brows + (2 * G + grp) * RS + kRowPad, lane, env0, act, hot, cur, dec, nsg);
 #ifdef MAPF_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
