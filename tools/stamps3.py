@@ -62,26 +62,7 @@ three = np.stack([rel[:, :, 9], rel[:, :, 14], rel[:, :, 31]])
 who = three.argmax(axis=0)
 print(f"  workgroup end: p99 {np.percentile(end, 99):.0f}  p99.9 {np.percentile(end, 99.9):.0f}; last wave of a workgroup: state {np.mean(who == 0):.2f} / obs {np.mean(who == 1):.2f} / aux {np.mean(who == 2):.2f}; "
       f"of the slowest 1 %: state {np.mean(who[end >= np.percentile(end, 99)] == 0):.2f} / obs {np.mean(who[end >= np.percentile(end, 99)] == 1):.2f} / aux {np.mean(who[end >= np.percentile(end, 99)] == 2):.2f}")
-# the launch as a whole: when the workgroups enter (dispatch ramp) and when the last one ends, after the first entry
-ent = full[:, :, 15]
-last = np.max(np.stack([full[:, :, 9], full[:, :, 14], full[:, :, 31]]), axis=0)
-# (s_memtime counters differ between XCDs: entries are taken relative to the first entry on the same XCD -- slot 3 holds the
-#  state wave's HW_REG_XCC_ID in bits 32-35; k_step without it: workgroup b is assumed to run on XCD b mod 8)
-hw3 = full[-1, :, 3]
-xcd = ((hw3 >> 32) & 0xF) if (hw3 >> 40).any() or full[:, :, 4].any() and False else (np.arange(ent.shape[1]) % 8)
-if (hw3 >> 32).any():
-    xcd = (hw3 >> 32) & 0xF
-t0 = np.zeros_like(ent)
-for x in np.unique(xcd):
-    m = xcd == x
-    t0[:, m] = np.where(ent[:, m] > 0, ent[:, m], np.iinfo(np.int64).max).min(axis=1, keepdims=True)
-ok = ent > 0
-rel_e, rel_l = np.where(ok, ent - t0, 0), np.where(ok, last - t0, 0)
-print(f"  launch: workgroup entries spread over {np.median(rel_e.max(axis=1)):.0f} cycles (median entry {np.median(rel_e[ok]):.0f}, p95 {np.percentile(rel_e[ok], 95):.0f}); "
-      f"last workgroup ends {np.median(rel_l.max(axis=1)):.0f} cycles after the first entry on its XCD (median workgroup {np.median(rel_l[ok]):.0f}, p95 {np.percentile(rel_l[ok], 95):.0f})")
-late = (ent - t0) > np.percentile(ent - t0, 90, axis=1, keepdims=True)
-print(f"  the 10 % of workgroups that enter last: duration median {np.median((last - ent)[late]):.0f}  (all: {np.median(last - ent):.0f})")
-kind = full[:, :, 23]
+kind = np.where(full[:, :, 4] > full[:, :, 15], full[:, :, 23], 0)  # (the buffer keeps a launch's stamps: a slice of THIS launch started after this launch's entry)
 if (kind > 0).any():
     print(f"  state waves running a draw slice (after B1) per launch (median): {np.median((kind > 0).sum(axis=1)):.0f}")
     for k in range(1, 8):
