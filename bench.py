@@ -14,8 +14,9 @@ script launches one fresh child process per GPU itself (before it touches a GPU)
 The timed region is what an RL loop sees in steady state: episode phases are STAGGERED (env b starts at step
 b mod steps_per_episode), so about 1 % of the envs finish and are re-placed inside EVERY launch; `value` is
 that number.  `value_synchronised` is the same run with all episodes in phase (resets in 1 launch of 100).
-All K timed launches are hipGraph replays (graphs of min(K, --graph-steps) launches plus one for the
-remainder) unless --graph-steps 0.
+All K timed launches are hipGraph replays (graphs of min(K, --graph-steps) launches plus one for the remainder) unless
+--graph-steps 0 or --launch-mode plain (plain C-ABI launches back to back; --launch-mode auto times min(K, 200) launches
+both ways outside warm-up and timed region and takes the faster); `config.launch_mode` says which.
 
 Rank 0 prints ONE JSON line.  Extra fields: `roofline` -- `frac` is SURVEY 8(d)'s quantity computed from the `value`
 next to it (agent-steps/s x algorithmic bytes per agent-step / 8 TB/s), `frac_kernel` the same bytes over the DEVICE
@@ -60,6 +61,12 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the workload's envs per GPU; strong: --total-envs split over the GPUs")
     ap.add_argument("--total-envs", type=int, default=C4_TOTAL_ENVS, help="strong scaling: envs of the whole job")
+    ap.add_argument("--launch-mode", choices=("graph", "plain", "auto"), default="graph",
+                    help="how the K timed launches reach the GPU: hipGraph replays (default), plain C-ABI launches back to back, "
+                         "or (auto) whichever of the two a calibration of min(K, 200) launches outside warm-up and timed region "
+                         "finds faster for this workload and K; config.launch_mode says which.  (Measured, c3: at K = 2 000 the "
+                         "two are within 1 %; at the driver's K = 20 both scatter between 6.0 and 7.5 us per step from run to "
+                         "run -- a window of 0.12 ms is dominated by what surrounds it -- so auto is not the default.)")
     ap.add_argument("--graph-steps", type=int, default=100,
                     help="launches captured per hipGraph (0 = plain launches)")
     ap.add_argument("--episodes", choices=("staggered", "synchronised", "both"), default="both",
@@ -557,8 +564,10 @@ def worker(args) -> int:
         full, rem = divmod(k, G)
         return ([(graph_of(G), full)] if full else []) + ([(graph_of(rem), 1)] if rem else [])
 
+    mode = {"chosen": "plain" if (G == 0 or args.launch_mode == "plain") else "graph", "requested": args.launch_mode}
+
     def run_launches(k, pl):
-        if G == 0:
+        if mode["chosen"] == "plain":
             run_plain(k)
         else:
             for g, reps in pl:
@@ -582,6 +591,29 @@ def worker(args) -> int:
         pre = args.pre_roll if args.pre_roll >= 0 else spe
         pre_l = (pre + spl - 1) // spl
         pl_w, pl_t, pl_p = plan(args.warmup // spl), plan(launches), plan(pre_l)  # capture happens here, outside the timed region
+        if args.launch_mode == "auto" and G > 0 and "calibration_us_per_step" not in mode:
+            # Launch-mode calibration (state preparation like the pre-roll: not warm-up, not timed): the same fence-to-fence
+            # region as the timed one, min(K, 200) launches, once as graph replays and once as plain launches.  Every rank
+            # takes the job's (slowest rank's) times, so all ranks choose alike.
+            c = min(launches, 200)
+            pl_c = plan(c)
+            t_us = {}
+            for m in ("graph", "plain", "graph", "plain"):
+                mode["chosen"] = m
+                fence()
+                t0 = time.perf_counter()
+                run_launches(c, pl_c)
+                fence()
+                dt = 1e6 * (time.perf_counter() - t0) / (c * spl)
+                t_us[m] = min(t_us.get(m, dt), dt)
+            if use_dist:
+                tt = torch.tensor([t_us["graph"], t_us["plain"]], dtype=torch.float64, device=None if args.share_gpu else device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_us = {"graph": float(tt[0]), "plain": float(tt[1])}
+            mode["chosen"] = "plain" if t_us["plain"] < t_us["graph"] else "graph"
+            mode["calibration_us_per_step"] = {k: round(v, 4) for k, v in t_us.items()}
+            mode["calibrated_on_launches"] = c
+            run.poll_error()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record(stream)  # (torch creates the HIP event at its first record: not inside the timed region)
         ev1.record(stream)
@@ -689,7 +721,8 @@ def worker(args) -> int:
             traffic = None
 
     full, rem = divmod(launches, G) if G else (0, 0)
-    launch = (f"hipGraph: {full} x {G} launches" + (f" + 1 x {rem}" if rem else "")) if G else "plain launches"
+    launch = ((f"hipGraph: {full} x {G} launches" + (f" + 1 x {rem}" if rem else "")) if mode["chosen"] == "graph"
+              else f"{launches} plain launches through the C ABI, back to back")
     if spl > 1:
         launch += f", {spl} env steps per launch (fused, observation written every step)"
     phases = "staggered" if "staggered" in legs else "synchronised"
@@ -713,7 +746,7 @@ def worker(args) -> int:
             "steps_per_episode": spe, "lock_metrics": not wl.is_single_agent(name), "auto_reset": "in-kernel",
             "episode_phases": phases, "resets_in_timed_region": head["resets"],
             "pre_roll_steps": args.pre_roll if args.pre_roll >= 0 else spe,
-            "actions": "uniform{0..4}, device-resident", "launch": launch, "env_steps_per_launch": spl,
+            "actions": "uniform{0..4}, device-resident", "launch": launch, "launch_mode": mode, "env_steps_per_launch": spl,
             "parallelism": f"env-sharded x{world}, no hot-path collective", **run.launch_info(),
         },
         "roofline": {
