@@ -5353,6 +5353,8 @@ struct CteIo {
     float *final_obs;
     const uint8_t *env_mask;
     int auto_reset;
+    int sampler_blocks;  // k_cte_step, single steps: workgroups at the FRONT of the grid that pre-draw next-episode placements
+    int lds_scratch2_off;  // the draw scratch of their second wave
 };
 
 // full-grid observation + joint mask of the groups' current state -> staging rows, in two parts: the obstacle
@@ -5626,7 +5628,19 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
     load_lane_hot(io.agents, (size_t)env * N + min(a, N - 1), is_agent, st);
     const bool do_reset = env_ok && (io.env_mask == nullptr || io.env_mask[env] != 0);
     wave_lds_sync();
-    if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st);
+    if (!(p.flags & MAPF_FLAG_DETERMINISTIC)) {
+        // a placement pre-drawn for the env's next episode (k_cte_step) IS what rng.choice returns now: its draw is in the
+        // stream already
+        const size_t si = (size_t)env * N + min(a, N - 1);
+        const uint32_t nsg = p.next_sg[si];
+        const bool slot_ok = gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
+        cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset && !slot_ok, is_agent, st);
+        if (do_reset && slot_ok && is_agent) {
+            st.start = nsg & 0xFFFFu;
+            st.goal = nsg >> 16;
+            p.next_sg[si] = kSlotInvalid;
+        }
+    }
     if (do_reset) {  // SA-env:222-232
         st.pos = st.start;
         st.flags = 0;
@@ -5645,6 +5659,7 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
         if (a == 0) {
             int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
             sp[0] = make_int4(0, 0, 0, 0);  // step_count, -, _episode_blocking_count, -
+            io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH] = 1;  // (conservative: the next step writes the real hint)
         }
     }
 }
@@ -5659,7 +5674,8 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
 // T > 1 (mapf_cte_step_many): the same two waves run T steps in one launch -- positions stay in registers, the obstacle
 // floats are written ONCE (after a row has left, the 2N cells the overlay touched are set back to 0: agents and goals
 // only ever stand on free cells), per step only the actions are read and the outputs written.
-constexpr uint32_t kCteWAgent = 1u, kCteWSelShift = 1u, kCteWReset = 8u;
+constexpr uint32_t kCteWAgent = 1u, kCteWSelShift = 1u, kCteWReset = 8u,
+                   kCteWFast = 16u;  // (with kCteWReset) the new placement is in entry word w already: no B2 for this env
 struct CteMany {
     int T;         // steps in this launch (1 = mapf_cte_step)
     int obs_mode;  // fused launches: 0 no observation, 1 after the last step only, 2 every step ([T][B][row])
@@ -5676,7 +5692,67 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
     int16_t *scratch = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch_off);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, grp = lane / LPE, a = lane % LPE;
-    const int env0 = blockIdx.x * G, ngroups = min(G, io.B - env0), N = p.N, H = io.H, W = io.W;
+    const int lead = FUSED ? 0 : io.sampler_blocks;
+    if (!FUSED && (int)blockIdx.x < lead) {
+        // ---- sampler workgroup (single-step launches with sampled placements): wave w looks after envs 64 (2 b + w) .. + 63 --
+        // an env without a placement for its next episode that CANNOT end its episode in this launch (the MAY_FINISH hint its
+        // last step left: somebody further than one move from its goal, step limit not due) gets one drawn here, beside the
+        // launch instead of inside its own workgroup's step: nobody else reads or writes its stream or slot in this launch.
+        const int sw = (int)blockIdx.x * 2 + wv;
+        int16_t *sscr = wv == 0 ? scratch : reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch2_off);
+        const int e = sw * 64 + lane;
+        bool need = false;
+        // (the env's stream and free-cell count come with the same round trip, speculatively: 52 bytes per env and launch)
+        uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0;
+        int sF = 0;
+        if (e < io.B) {
+            const uint32_t w0 = p.next_sg[(size_t)e * p.N];
+            const int hint = io.scal[(size_t)e * kScalInts + MAPF_CTR_MAY_FINISH];
+            const uint4 *rw = reinterpret_cast<const uint4 *>(p.rng + (size_t)e * 6);
+            s0 = rw[0];
+            s1 = rw[1];
+            s2 = rw[2];
+            sF = p.n_free[e];
+            need = w0 == kSlotInvalid && hint == 0;
+        }
+        uint64_t todo = __ballot(need);
+        // ONE round per launch -- G envs, one per lane group; the others wait for the next launch: a round (~5 k cycles) ends
+        // well inside the step beside it, a wave that drew all 64 of its envs in the launch after they were re-placed together
+        // (episodes in phase) was the launch's last by 8 rounds (5.24 us per step in phase against 4.98; one round: below)
+        if (todo) {
+            int pick = -1;
+            uint64_t m = todo;
+            for (int g = 0; g < G; g++) {
+                const int j = m ? (int)__builtin_ctzll(m) : -1;
+                if (m) m &= m - 1;
+                if (g == grp) pick = j;
+            }
+            todo = m;
+            const bool on = pick >= 0;
+            const int env_s = on ? sw * 64 + pick : 0;
+            // the picked env's stream sits in lane `pick` of the wave: hand it to lane 0 of the group that draws it
+            CtePre spre{true, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+            {
+                const int src = on ? pick : 0;
+                spre.w0 = make_uint4(__shfl(s0.x, src), __shfl(s0.y, src), __shfl(s0.z, src), __shfl(s0.w, src));
+                spre.w1 = make_uint4(__shfl(s1.x, src), __shfl(s1.y, src), __shfl(s1.z, src), __shfl(s1.w, src));
+                spre.w2 = make_uint4(__shfl(s2.x, src), __shfl(s2.y, src), __shfl(s2.z, src), __shfl(s2.w, src));
+                spre.F = __shfl(sF, src);
+            }
+            if (on && a == 0) {  // the visible stream of an env whose placement is pending: the state before this draw
+                uint4 *vw = reinterpret_cast<uint4 *>(p.vis_rng + (size_t)env_s * 6);
+                vw[0] = spre.w0;
+                vw[1] = spre.w1;
+                vw[2] = spre.w2;
+            }
+            Lane drawn;
+            drawn.start = drawn.goal = 0u;
+            cte_sample_starts_goals<LPE>(p, p.N, sscr, grp, a, env_s, on, on && a < p.N, drawn, spre);
+            if (on && a < p.N) p.next_sg[(size_t)env_s * p.N + a] = (drawn.start & 0xFFFFu) | (drawn.goal << 16);
+        }
+        return;
+    }
+    const int env0 = ((int)blockIdx.x - lead) * G, ngroups = min(G, io.B - env0), N = p.N, H = io.H, W = io.W;
     const bool env_ok = grp < ngroups;
     const int env = env_ok ? env0 + grp : io.B - 1;
     const bool is_agent = env_ok && a < N;
@@ -5714,7 +5790,9 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
                 // staggered step took after the draw had been made lane-parallel.)
                 const bool rs0 = (ent.z & kCteWReset) != 0;
                 cte_overlay<LPE>(io, srow, ag && !rs0, a, ent.x, ent.y);
-                wg_sync();  // B2: the placement is in the table
+                // B2: the placement an env drew inline is in the table -- only when some env of the workgroup HAD to draw: a
+                // pre-drawn placement (kCteWFast) came with the entry
+                if (__any((ent.z & (kCteWReset | kCteWFast)) == kCteWReset)) wg_sync();
                 const uint4 e2 = (otab + (t & 1) * 64)[lane];
                 cte_overlay<LPE>(io, srow, ag && rs0, a, e2.w & 0xFFFFu, e2.w >> 16);
                 flush_rows<KRuntime, LPE>(fio, stage, lane, env0, ngroups, rs0 ? 0 : (int)((ent.z >> kCteWSelShift) & 3u), row_len);
@@ -5745,7 +5823,7 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
                 // streaming the step's rows out (B2: that placement is in the table).  (Round 3: the state wave waited for
                 // this wave's flush, drew, rebuilt the whole row itself and flushed: 13.1 us per step with staggered episodes
                 // against 5.0 in phase.)
-                wg_sync();  // B2
+                if (__any((ent.z & (kCteWReset | kCteWFast)) == kCteWReset)) wg_sync();  // B2 (as above)
                 const uint4 e2 = (otab + (t & 1) * 64)[lane];
                 const bool rs = ag && (e2.z & kCteWReset) != 0;
                 if (fio.obs) {
@@ -5785,6 +5863,10 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
             pre.F = p.n_free[env];
         }
     }
+    // the placement pre-drawn for the env's NEXT episode (k_cte_step draws it in the step after a reset, off every path a
+    // step waits for): start | goal << 16 per agent, kSlotInvalid = none.  While it is pending the env's stream array holds
+    // the state AFTER that draw and Params::vis_rng the visible one (the multi-agent engine's slots; mapf_get_state knows)
+    uint32_t nsg = (p.flags & MAPF_FLAG_DETERMINISTIC) ? kSlotInvalid : p.next_sg[idx];
     int step_count = sc0.x, blocking_total = sc0.z;
 
     // (the actions of step t + 1 are requested while step t is computed: in a fused launch that load's latency would
@@ -5831,6 +5913,11 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
         else if (step_now >= io.steps_per_episode) term = trunc = 1;
         const bool done = env_ok && !errored && (term | trunc);
         const bool do_reset = done && (fused || io.auto_reset);
+        const bool sampled = !(p.flags & MAPF_FLAG_DETERMINISTIC);
+        const bool slot_ok = sampled && gballot<LPE>(is_agent && !slot_word_valid(nsg), lane) == 0;
+        // the placement a reset installs is known HERE: the pre-drawn one, or (fixed starts) the start table's
+        const bool fast = do_reset && (slot_ok || !sampled);
+        const uint32_t place = slot_ok ? nsg : ((st.start & 0xFFFFu) | (st.goal << 16));
 
         // observation after ALL moves (SA-env:288-293): hand the new positions to the observation wave
         {
@@ -5839,7 +5926,9 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
             //  terminal row goes nowhere)
             const int sel_f = (fused && do_reset) ? 2 : sel;
             (otab + (t & 1) * 64)[lane] = make_uint4(cur, st.goal, (is_agent ? kCteWAgent : 0u) | ((uint32_t)sel_f << kCteWSelShift) |
-                                                                      ((do_reset && want_obs) ? kCteWReset : 0u), 0u);
+                                                                      ((do_reset && want_obs) ? kCteWReset : 0u) |
+                                                                      ((fast && want_obs) ? kCteWFast : 0u),
+                                                     fast ? place : 0u);
         }
         wg_sync();  // B1
 
@@ -5893,19 +5982,51 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
         st.flags = reached_once ? kFlagReached : 0;
         step_count = step_now;  // (also when the ValueError fires: SA-env:247 increments first)
 
-        if (__any(do_reset)) {
-            // the draw runs beside the observation wave's stream (it only touches the group's scratch); the reset observation
-            // is that wave's (it has the obstacle floats in place): the placement goes to it through the table, behind B2
-            if (!(p.flags & MAPF_FLAG_DETERMINISTIC))
-                cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, do_reset, is_agent, st, pre);
+        // Who draws in this step: an env that ends its episode without a pre-drawn placement (inline: the observation wave
+        // waits for it at B2), and -- single-step launches -- an env that has none for its NEXT episode and does not end one now
+        // (background: nobody waits; the stream was fetched with the wave's first loads).  One call serves both.
+        const bool slow = do_reset && !fast;
+        // (round 4, first version: drawn here, by this wave behind its outputs -- 7.75 us per staggered step against 8.34 without
+        //  any pre-draw: the draw still made its workgroup the launch's last.  The sampler workgroups at the front of the grid do
+        //  it now; without them -- fused launches never have them -- nothing is pre-drawn.)
+        const bool predraw = false;
+        const bool any_slow = __any(slow);
+        if (__any(do_reset) || __any(predraw)) {
+            Lane drawn = st;
+            if (__any(slow || predraw)) {
+                if (predraw && a == 0) {  // the visible stream of an env whose placement is pending (before the draw advances it)
+                    uint4 *vw = reinterpret_cast<uint4 *>(p.vis_rng + (size_t)env * 6);
+                    vw[0] = pre.w0;
+                    vw[1] = pre.w1;
+                    vw[2] = pre.w2;
+                }
+                cte_sample_starts_goals<LPE>(p, N, scratch, grp, a, env, slow || predraw, is_agent, drawn, pre);
+            }
+            if (predraw && is_agent) {
+                nsg = (drawn.start & 0xFFFFu) | (drawn.goal << 16);
+                p.next_sg[idx] = nsg;
+            }
             if (do_reset) {
+                if (slot_ok) {  // the pre-drawn placement (its draw is in the stream already); the slot is consumed
+                    if (is_agent) {  // (idle lanes keep their idle cell: they take part in the move table)
+                        st.start = nsg & 0xFFFFu;
+                        st.goal = nsg >> 16;
+                        nsg = kSlotInvalid;
+                        if (!fused) p.next_sg[idx] = kSlotInvalid;
+                    }
+                } else if (sampled) {
+                    st.start = drawn.start;
+                    st.goal = drawn.goal;
+                }
                 st.pos = st.start;
                 st.flags = 0;
                 step_count = 0;
                 blocking_total = 0;
             }
-            if (want_obs) {
-                (otab + (t & 1) * 64)[lane].w = (st.pos & 0xFFFFu) | (st.goal << 16);
+            if (want_obs && any_slow) {
+                // the reset observation is the observation wave's (it has the obstacle floats in place): an inline draw's
+                // placement goes to it through the table, behind B2
+                if (slow) (otab + (t & 1) * 64)[lane].w = (st.pos & 0xFFFFu) | (st.goal << 16);
                 wg_sync();  // B2
             }
         }
@@ -5913,9 +6034,16 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
         pass = is_agent ? agent_pass_bits(myrows, st.pos, io.col_pad, W) : 0u;
     }
     if (is_agent) store_lane_hot(io.agents, (size_t)env * N + a, st, pass);
-    if (env_ok && a == 0) {
-        int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
-        sp[0] = make_int4(step_count, 0, blocking_total, 0);
+    if (fused && is_agent && !(p.flags & MAPF_FLAG_DETERMINISTIC)) p.next_sg[idx] = nsg;  // (consumed by a reset of this launch, or as it was)
+    {   // MAY_FINISH hint for the sampler workgroups of the NEXT launch: the env can end its episode in its next step iff the
+        // step limit is due or every agent is within one move of its goal (SA-env:327-336: all on their goals at once)
+        const bool far = is_agent && cell_l1(st.pos, st.goal) > 1;
+        const bool may = gballot<LPE>(far, lane) == 0 || step_count + 1 >= io.steps_per_episode;
+        if (env_ok && a == 0) {
+            int4 *sp = reinterpret_cast<int4 *>(io.scal + (size_t)env * kScalInts);
+            sp[0] = make_int4(step_count, 0, blocking_total, 0);
+            io.scal[(size_t)env * kScalInts + MAPF_CTR_MAY_FINISH] = may ? 1 : 0;
+        }
     }
 }
 

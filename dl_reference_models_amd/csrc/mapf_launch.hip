@@ -102,7 +102,7 @@ hipError_t MAPF_CAT4(launch_runtime_many_, MAPF_TU_LPE, _, MAPF_TU_MW)(const Lau
 hipError_t MAPF_CAT(launch_cte_, MAPF_TU_CTE)(const LaunchPlan &lp, const CteIo &io, bool step, hipStream_t s, CteMany many) {
     constexpr int L = MAPF_TU_CTE;
     if (step && many.T > 1) LAUNCH_CHECKED((k_cte_step<L, true>), dim3(lp.blocks), dim3(128), lp.lds_bytes, s, lp.d_params, io, many);
-    if (step) LAUNCH_CHECKED((k_cte_step<L, false>), dim3(lp.blocks), dim3(128), lp.lds_bytes, s, lp.d_params, io, many);
+    if (step) LAUNCH_CHECKED((k_cte_step<L, false>), dim3(lp.blocks + io.sampler_blocks), dim3(128), lp.lds_bytes, s, lp.d_params, io, many);
     LAUNCH_CHECKED((k_cte_reset<L>), dim3(lp.blocks), dim3(64), lp.lds_bytes, s, lp.d_params, io);
 }
 #endif

@@ -78,6 +78,7 @@ struct mapf_engine {
     int use_map = 0, lds_map_off = 0;  // LDS cell-map path of wide groups
     double cte_blocking_penalty = -0.2, cte_move_after_goal_penalty = -0.05;  // SA-env:92-93
     // single-agent env, fused launches (mapf_cte_step_many, T > 1): their own group width and LDS layout (mapf_create)
+    int cte_scratch2_off = 0;
     struct CteManyPlan { int lpe = 0, blocks = 0, lds_bytes = 0, tab_off = 0, stage_off = 0, scratch_off = 0; } cte_many;
     int blocks = 0;
     int sampler_blocks = 0;  // k_step only: workgroups appended to the grid that pre-draw next-episode placements
@@ -795,6 +796,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.lds_stage_off = rows_bytes + tab_bytes;
     p.lds_scratch_off = rows_bytes + tab_bytes + stage_bytes;
     e->lds_bytes = rows_bytes + tab_bytes + stage_bytes + scratch_bytes;
+    if (cte) {  // a second draw scratch: both waves of a sampler workgroup of k_cte_step draw (CteIo::lds_scratch2_off)
+        e->cte_scratch2_off = e->lds_bytes;
+        e->lds_bytes += scratch_bytes;
+    }
     {   // wide groups (N > 16): per-env cell map in LDS instead of the all-pairs walk, when it fits and the lock
         // neighbourhood stays inside the map's border
         const int map_bytes = ((G * (H + 2 * kRowPad) * (W + 2 * kRowPad) * 4) + 15) & ~15;
@@ -1381,6 +1386,11 @@ int mapf_step_many_sampled(mapf_handle e, int32_t T, const float *obs_in, uint64
                           info_agent, stream);
 }
 
+// single-step launches of the single-agent env with sampled placements: one sampler workgroup per 64 envs at the front of the
+// grid (k_cte_step: it pre-draws the next placement of the envs that have none and cannot end their episode in this launch)
+static int cte_sampler_blocks(const mapf_engine *e) {  // (both waves of a sampler workgroup work: 128 envs each)
+    return (e->cfg.flags & MAPF_FLAG_DETERMINISTIC) ? 0 : (e->p.B + 127) / 128;
+}
 static CteIo make_cte_io(const mapf_engine *e, bool fused = false) {
     CteIo io;
     memset(&io, 0, sizeof io);
@@ -1396,6 +1406,7 @@ static CteIo make_cte_io(const mapf_engine *e, bool fused = false) {
     io.lds_tab_off = fused ? e->cte_many.tab_off : e->p.lds_tab_off;
     io.lds_stage_off = fused ? e->cte_many.stage_off : e->p.lds_stage_off;
     io.lds_scratch_off = fused ? e->cte_many.scratch_off : e->p.lds_scratch_off;
+    io.lds_scratch2_off = e->cte_scratch2_off;
     io.blocking_penalty = e->cte_blocking_penalty;
     io.move_after_goal_penalty = e->cte_move_after_goal_penalty;
     return io;
@@ -1447,6 +1458,7 @@ int mapf_cte_step(mapf_handle e, const int8_t *actions, float *obs, double *rewa
     io.info = info;
     io.final_obs = final_obs;
     io.auto_reset = auto_reset;
+    io.sampler_blocks = cte_sampler_blocks(e);
     ON_DEVICE(e);
     LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
     return MAPF_OK;
@@ -1469,6 +1481,7 @@ int mapf_cte_step_many(mapf_handle e, int32_t T, const int8_t *actions, float *o
     ON_DEVICE(e);
     if (T == 1) {  // (the single-step kernel shape: obs_mode 0 = no observation)
         if (obs_mode == 0) io.obs = nullptr;
+        io.sampler_blocks = cte_sampler_blocks(e);
         LAUNCH_TRY(e, launch_cte(e, io, true, (hipStream_t)stream));
         return MAPF_OK;
     }
