@@ -507,3 +507,68 @@ def test_single_agent_env_staggered_resets_match_the_oracle(lanes, B, H, W, N, s
     _eq("positions", eng.positions(), orc.positions())
     _eq("goals", eng.goals(), orc.goals())
     eng.env.poll_error()
+
+
+# ---- single-agent env: next-episode placements pre-drawn by sampler workgroups -------------------------------------------
+def _cte_slots(eng):
+    import ctypes as C
+    B, N = eng.B, eng.N
+    sl = np.zeros(B * N, np.uint32)
+    eng.env._lib.mapf_debug_slots(eng.env._h, sl.ctypes.data_as(C.c_void_p), None, None)
+    return sl.reshape(B, N)
+
+
+@pytest.mark.parametrize("B,H,W,N,spe,lanes", [(200, 16, 16, 4, 7, 0), (70, 32, 32, 8, 5, 0), (33, 10, 10, 12, 2, 16), (130, 9, 7, 5, 11, 8)])
+def test_single_agent_env_predrawn_placements(B, H, W, N, spe, lanes):
+    """Single-step launches of the single-agent env carry sampler workgroups that draw the NEXT episode's placement of an
+    env that has none and cannot end its episode in that launch; a reset then takes it (no inline draw).  While a placement
+    is pending the stream array is one draw ahead and `get_state` reports the VISIBLE stream -- compared with the oracle's
+    generator after EVERY step, with staggered phases; slots do get filled and consumed; an explicit `reset(env_mask)`
+    consumes them too; fused launches in between take and leave them as they are."""
+    import torch
+
+    from trace_util import CteEngineStepper, CteOracleStepper
+
+    cfg = {"env_name": "synthetic", "num_agents": N, "steps_per_episode": spe}
+    grids = synth_grids(B, H, W, 0.15, N, base_seed=99_000)
+    seeds = list(range(300, 300 + B))
+    a = CteEngineStepper(grids, cfg, seeds=seeds, lanes_per_env=lanes)
+    b = CteOracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset obs", a.reset(), b.reset())
+    counts = np.arange(B) % spe
+    a.env.set_step_counts(counts)
+    for e, c in zip(b.envs, counts):
+        e._step[0] = int(c)
+    rng = np.random.default_rng(8)
+    seen_valid = 0
+    for t in range(6 * spe + 9):
+        acts = rng.integers(0, 5, size=(B, N)).astype(np.int8)
+        ra, rb = a.step(acts), b.step(acts)
+        for k in ("obs", "reward", "terminated", "truncated", "info"):
+            _eq(k, ra[k], rb[k], t)
+        done = (rb["terminated"] | rb["truncated"]).astype(bool)
+        if done.any():
+            _eq("final_obs", ra["final_obs"][done], rb["final_obs"][done], t)
+        _eq("visible stream", a.rng_words(), b.rng_words(), t)
+        seen_valid = max(seen_valid, int((_cte_slots(a)[:, 0] < 0xFFFFFFF0).sum()))
+        if t == 2 * spe + 1:  # an explicit reset of some envs: pending placements are what rng.choice returns
+            mask = (np.arange(B) % 3 == 0)
+            oa = a.env.reset(env_mask=torch.from_numpy(mask.astype(np.uint8))).cpu().numpy()
+            for i in np.nonzero(mask)[0]:
+                _eq(f"explicit reset obs of env {i}", oa[i], b.envs[i].reset(), t)
+            _eq("visible stream after reset", a.rng_words(), b.rng_words(), t)
+        if t == 4 * spe:  # a fused launch in between
+            T = spe + 3
+            acts_t = rng.integers(0, 5, size=(T, B, N)).astype(np.int8)
+            out = a.env.step_many(torch.from_numpy(acts_t).to(a.env.device), obs_mode=2)
+            refs = [b.step(acts_t[k]) for k in range(T)]
+            _eq("fused obs", out["obs"].cpu().numpy(), np.stack([r["obs"] for r in refs]), t)
+            _eq("visible stream after the fused launch", a.rng_words(), b.rng_words(), t)
+    _eq("positions", a.positions(), b.positions())
+    _eq("goals", a.goals(), b.goals())
+    # (a sampler wave draws for one env per lane group and launch: short episodes on wide groups outrun it and most resets
+    #  draw inline -- both paths are in the comparison above; episodes of two steps are never pre-drawn: the step limit is
+    #  always one step away)
+    if spe > 2:
+        assert seen_valid >= 4, seen_valid
+    a.env.poll_error()
