@@ -120,6 +120,10 @@ def config_flags(cfg: dict) -> int:
     return f
 
 
+# the current stream's raw handle without building a torch.cuda.Stream object per call (0.5 us of a 7 us Python step)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 class VecReferenceModel:
     def __init__(self, env_config: dict):
         cfg = dict(env_config)
@@ -206,6 +210,7 @@ class VecReferenceModel:
                     setattr(self, name, self._out_blob[off:off + sz].view(dt).view(shape))
 
         self._act_shape = torch.Size((B, N))
+        self._dev_index = int(self.device.index)
         self._step_fn = self._lib.mapf_step_bound  # (four arguments per call instead of eleven: mapf_bind_outputs)
         self._check(self._lib.mapf_bind_outputs(self._h, self._obs.data_ptr(), self._rewards.data_ptr(), self._terminated.data_ptr(),
                                                 self._truncated.data_ptr(), self._info_all.data_ptr(), self._info_agent.data_ptr()))
@@ -242,7 +247,7 @@ class VecReferenceModel:
 
     # ------------------------------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(_raw_stream(int(self.device.index)))
 
     def _check(self, rc: int, exc=RuntimeError):
         if rc != L.MAPF_OK:
@@ -288,8 +293,7 @@ class VecReferenceModel:
         if env_mask is None and not want_final_obs:
             # the common call of a rollout loop: every pointer but the actions' is fixed for the life of the handle and bound to
             # it once (mapf_bind_outputs); the per-call cost is one data_ptr(), the stream and a four-argument ctypes call
-            rc = self._step_fn(self._h, actions.data_ptr(), 1 if auto_reset else 0,
-                               torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self._step_fn(self._h, actions.data_ptr(), 1 if auto_reset else 0, _raw_stream(self._dev_index))
             if rc != 0:
                 self._check(rc)
             return self._step_out

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib as L
 from . import get_grid as grid_tables
-from .vec_env import pcg64_words
+from .vec_env import _raw_stream, pcg64_words
 
 INFO_KEYS = ("blocking_count_step", "goals_reached_step", "goals_reached_total", "blocking_count_total")
 
@@ -83,7 +83,7 @@ class VecSingleAgentReferenceModel:
             self._check(self._lib.mapf_cte_reset(h, None, None, self._stream()))
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(_raw_stream(int(self.device.index)))
 
     def _check(self, rc, exc=RuntimeError):
         if rc != L.MAPF_OK:
