@@ -403,6 +403,34 @@ def test_sixteen_lane_groups_with_and_without_bit_rows_match_the_oracle(H, W, ov
         eng.env.poll_error()
 
 
+def test_sixteen_lane_groups_kernel_compiled_at_creation_uses_the_bit_rows_too():
+    """`jit_specialize=True` on a 16-agent configuration that is not prebuilt: the kernel hiprtc compiles at creation is the
+    three-wave kernel with the bit-row paths (same launch plan, same LDS) -- against the oracle, staggered episode ends."""
+    n, B, H, W = 16, 26, 18, 23
+    cfg = {"env_name": "synthetic", "num_agents": n, "sensor_range": 2, "include_action_mask_in_obs": True, "include_goal_distance": True,
+           "steps_per_episode": 8}
+    grids = synth_grids(B, H, W, 0.1, n, base_seed=96_500)
+    seeds = list(range(B))
+    eng = EngineStepper(grids, cfg, seeds=seeds, jit_specialize=True)
+    info = eng.env.launch_info()
+    if not info["jit"]:
+        pytest.skip(f"no run-time compilation here: {info['jit_note']}")
+    assert info["threads"] == 192
+    orc = OracleStepper(grids, cfg, seeds=seeds)
+    _eq("reset", eng.reset(), orc.reset())
+    counts = np.arange(B) % 8
+    eng.set_step_counts(counts)
+    orc.set_step_counts(counts)
+    rng = np.random.default_rng(21)
+    for t in range(50):
+        a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        ra, rb = eng.step(a), orc.step(a)
+        for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
+            _eq(k, ra[k], rb[k], t)
+    _eq("rng words", eng.rng_words(), orc.rng_words())
+    eng.env.poll_error()
+
+
 def test_sixteen_lane_groups_unreached_agent_standing_on_its_goal():
     """The case the intent rows cannot decide before the moves: an agent that has not "reached" its goal but stands on it
     (an injected state), or whose target is its goal -- it publishes its intent iff it does not end the step there."""
