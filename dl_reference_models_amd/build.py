@@ -59,7 +59,7 @@ VARIANTS = {
     # kernels uses (groups of 4 and 8 lanes, 5 x 5 windows).  Selected per handle with MAPF_CHECK_BUILD=1 (_lib.load);
     # tests/test_soak_gpu.py runs soaks on it.
     "check": (os.path.join(CSRC, "libmapfstep_check.so"), ["-DMAPF_CHECK", "-DMAPF_SMALL_SHAPES"],
-              _units((1, 2, 4, 5), [(4, 32), (8, 32)], ())),
+              _units((1, 2, 4, 5, 6), [(4, 32), (8, 32), (16, 32), (4, 64), (8, 64), (16, 64)], ())),
     # development builds (into build_diag/, never shipped): one shape each, -DMAPF_DEV turns the environment knobs on
     "dev_c3": (os.path.join(ROOT, "build_diag", "libdev.so"), ["-DMAPF_DEV", "-DMAPF_DEV_C3"], _units((1,), [(8, 32)], ())),
     "dev_c5": (os.path.join(ROOT, "build_diag", "libc5.so"), ["-DMAPF_DEV", "-DMAPF_DEV_C5"], _units((3,), [(64, 32)], ())),

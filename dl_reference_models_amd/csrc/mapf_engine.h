@@ -38,9 +38,9 @@ namespace mapfk {
 #elif defined(MAPF_DEV_C5)  // the c5 shape only -- one wavefront per env, 5 x 5 windows
 #define MAPF_FOR_LPE(X) X(64)
 #define MAPF_FOR_MW(X, L) X(L, 32)
-#elif defined(MAPF_SMALL_SHAPES)  // the checking build: groups of 4 and 8 lanes, windows up to 5 x 5
-#define MAPF_FOR_LPE(X) X(4) X(8)
-#define MAPF_FOR_MW(X, L) X(L, 32)
+#elif defined(MAPF_SMALL_SHAPES)  // the checking build: groups of 4, 8 and 16 lanes, windows up to 7 x 7
+#define MAPF_FOR_LPE(X) X(4) X(8) X(16)
+#define MAPF_FOR_MW(X, L) X(L, 32) X(L, 64)
 #else
 #define MAPF_FOR_LPE(X) X(4) X(8) X(16) X(32) X(64)
 #define MAPF_FOR_MW(X, L) X(L, 32) X(L, 64) X(L, 128)

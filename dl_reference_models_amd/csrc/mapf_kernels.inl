@@ -879,7 +879,8 @@ __device__ __forceinline__ void raise_error(const Params &p, int code, int env, 
 // lane groups that were not drawing, out[inv[..]] landing in a neighbour group's scratch) only showed as a wrong goal
 // cell 200 soak cases later; this build reports it at the store.  Sites: 1 raw outputs, 2 bounded draws, 3 shuffle
 // scatter (16 values), 4 shuffle scatter (128 values), 5 sequential Floyd hash / output, 6 free-cell gather index,
-// 7 cell-map index, 8 staging row, 9 slice staging, 10 scratch layout.
+// 7 cell-map index, 8 staging row, 9 slice staging, 10 scratch layout, 11 bit-row index (k_step3 with bit rows: goal / old-cell /
+// intent rows and the window rows read from them).
 #ifdef MAPF_CHECK
 #define MAPF_CHK(P, cond, site, env, val)                                                   \
     do {                                                                                    \
@@ -3484,6 +3485,7 @@ __device__ __forceinline__ void obs_candidate_rows(const Params &p, const Io &io
     const int V = K::V(p), sr = K::sr(p);
     const int r0 = (int)(cell >> 8) - sr, sh = (int)(cell & 255u) - sr + io.col_pad;
     const uint32_t vm = (1u << V) - 1u;
+    MAPF_CHK(p, r0 >= -kRowPad && r0 + V <= io.H + kRowPad && sh >= 0 && sh + V <= 64, 11, -1, cell);
     uint64_t rg[MAXV], rq[MAXV];
 #pragma unroll
     for (int d = 0; d < MAXV; d++) {  // (all reads of the window issue back to back)
@@ -3563,19 +3565,23 @@ __device__ __forceinline__ bool foresee_subst(const Io &io, int lane, int step_c
 // aux wave, before B1: the bit rows (cleared by this wave at entry) and its half of both candidates -> LDS
 template <class K, int LPE, int MW>
 __device__ __forceinline__ void aux3_prepare_rows(const Params &p, const Io &io, uint64_t *brows, const int lane, const uint2 hot,
-                                                  const int act, const int step_count_in, const uint32_t nsg) {
+                                                  const int act, const int step_count_in, const uint32_t nsg, const int env) {
     constexpr int G = 64 / LPE;
     const int grp = lane / LPE;
+    (void)env;
     const int RS = io.H + 2 * kRowPad;
     (void)p;
     const bool fs = foresee_subst<LPE>(io, lane, step_count_in, nsg);
     const uint32_t old = fs ? (nsg & 0xFFFFu) : (hot.x & 0xFFFFu), goal = fs ? (nsg >> 16) : (hot.x >> 16);
     uint64_t *goalb = brows + grp * RS + kRowPad, *occO = brows + (G + grp) * RS + kRowPad;
+    MAPF_CHK(p, (int)(goal >> 8) < io.H && (int)(old >> 8) < io.H && (int)((goal & 255u) + io.col_pad) < 64 && (int)((old & 255u) + io.col_pad) < 64,
+             11, env, (goal << 16) | old);
     atomicOr(reinterpret_cast<unsigned long long *>(&goalb[goal >> 8]), 1ull << ((goal & 255u) + io.col_pad));
     atomicOr(reinterpret_cast<unsigned long long *>(&occO[old >> 8]), 1ull << ((old & 255u) + io.col_pad));
     {   // intents of the step itself (never of the placement a foreseen reset shows)
         const IntentOf t = intent_of(io, hot.x & 0xFFFFu, hot.x >> 16, (hot.y >> 16) & 0xFFu, hot.y >> 24, act);
         uint64_t *irow0 = brows + (2 * G + grp) * RS + kRowPad;
+        MAPF_CHK(p, !t.sure || (t.row >= -kRowPad && t.row < io.H + kRowPad && t.bit >= 0 && t.bit < 64), 11, env, (t.row << 8) | (t.bit & 255));
         if (t.sure) atomicOr(reinterpret_cast<unsigned long long *>(&irow0[t.row]), 1ull << t.bit);
     }
 }
@@ -3781,7 +3787,7 @@ __device__ __forceinline__ void aux3_wave(const Params &p, const Io &io, const L
 
     MAPF_STAMP_W2(21);
     if constexpr (k3_rows<LPE, MW>()) {
-        if (brows) aux3_prepare_rows<K, LPE, MW>(p, io, brows, lane, raw.h, act, sc[MAPF_CTR_STEP_COUNT], nsg);
+        if (brows) aux3_prepare_rows<K, LPE, MW>(p, io, brows, lane, raw.h, act, sc[MAPF_CTR_STEP_COUNT], nsg, env);
     }
     MAPF_STAMP_W2(20);
     wg_sync();  // B1: the moves are published
@@ -6066,7 +6072,8 @@ constexpr uint32_t kFlagsRefDefault = MAPF_FLAG_NORMALIZE_GOAL_DELTA | MAPF_FLAG
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)   \
     X(2, 4, 2, kFlagsHeadline, 8, 16, 2, 1, 4)   \
     X(4, 8, 2, kFlagsRefDefault, 8, 16, 2, 1, 8) \
-    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4)
+    X(5, 4, 2, kFlagsRefDefault, 8, 16, 2, 1, 4) \
+    X(6, 16, 3, kFlagsRefDefault, 8, 16, 2, 1, 16)
 #else
 #define MAPF_SPECIALIZATIONS(X)                                            \
     X(1, 8, 2, kFlagsHeadline, 8, 16, 2, 1, 8)                              \

@@ -695,9 +695,13 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     if (lpe != 16 || c.sensor_range != 3 || cte)
         return fail(nullptr, MAPF_ERR_CONFIG, "this development build only holds 16-lane groups with 7 x 7 windows");
 #endif
-#if defined(MAPF_DEV_C3) || defined(MAPF_SMALL_SHAPES)
+#if defined(MAPF_DEV_C3)
     if ((lpe != 4 && lpe != 8) || c.sensor_range > 2 || cte)
-        return fail(nullptr, MAPF_ERR_CONFIG, "this reduced build (development / checking) only holds groups of 4 and 8 lanes with windows up to 5 x 5");
+        return fail(nullptr, MAPF_ERR_CONFIG, "this development build only holds groups of 4 and 8 lanes with windows up to 5 x 5");
+#endif
+#if defined(MAPF_SMALL_SHAPES)
+    if (lpe > 16 || c.sensor_range > 3 || cte)
+        return fail(nullptr, MAPF_ERR_CONFIG, "this reduced build (checking) only holds groups of 4, 8 and 16 lanes with windows up to 7 x 7");
 #endif
     mapf_engine *e = new mapf_engine();
     e->cfg = c;

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("master,cases,only_n,dense,check", [
     (2026, 40, None, None, False), (77, 30, 4, None, False), (4711, 30, None, "1", False), (1616, 25, 16, None, False),
-    (1617, 15, 16, "1", False), (2027, 30, None, None, True), (2028, 15, None, "1", True)])
+    (1617, 15, 16, "1", False), (2027, 30, None, None, True), (2028, 15, None, "1", True), (2029, 20, 16, None, True)])
 def test_short_soak_matches_oracle(master, cases, only_n, dense, check, monkeypatch):
     """dense = "1": the 128-register two-wave build of the specialised step kernels (k_step's WPS = 4: no speculative
     slice loads, slot word fetched lazily), which mapf_create otherwise only picks for grids of more than three waves per
