@@ -449,9 +449,14 @@ def test_sixteen_lane_groups_unreached_agent_standing_on_its_goal():
                 orc.batch.envs[b].goals[:] = pos[b]
                 orc.batch.envs[b].rebuild_owner_maps()
         a = rng.integers(0, 5, size=(B, n)).astype(np.int8)
+        if t == 19:  # everybody stays on its goal: the episode ends by SUCCESS, long before the step limit -- a reset
+            a[::2] = 0  # observation the preparing waves did not see coming (the table-walk fallback), in every other env
         ra, rb = eng.step(a), orc.step(a)
+        if t == 19:
+            assert rb["terminated"][::2].all() and not rb["truncated"][::2].any()
         for k in ("obs", "rewards", "terminated", "truncated", "info_all", "info_agent"):
             _eq(k, ra[k], rb[k], t)
+    _eq("rng words", eng.rng_words(), orc.rng_words())
     eng.env.poll_error()
 
 
