@@ -5360,7 +5360,7 @@ struct CteIo {
     const uint8_t *env_mask;
     int auto_reset;
     int sampler_blocks;  // k_cte_step, single steps: workgroups at the FRONT of the grid that pre-draw next-episode placements
-    int lds_scratch2_off;  // the draw scratch of their second wave
+    int lds_scratch2_off;  // the draw scratch of their two waves (cte_sampler_groups groups each)
 };
 
 // full-grid observation + joint mask of the groups' current state -> staging rows, in two parts: the obstacle
@@ -5682,6 +5682,46 @@ __global__ __launch_bounds__(64) void k_cte_reset(const Params *__restrict__ pp,
 // only ever stand on free cells), per step only the actions are read and the outputs written.
 constexpr uint32_t kCteWAgent = 1u, kCteWSelShift = 1u, kCteWReset = 8u,
                    kCteWFast = 16u;  // (with kCteWReset) the new placement is in entry word w already: no B2 for this env
+// lane groups of a sampler wave of k_cte_step: 8 or 16 lanes when the agents fit and the step's groups are wider, else the step's
+__host__ __device__ constexpr int cte_sampler_lanes(int N, int lpe) { return (N <= 8 && lpe > 8) ? 8 : ((N <= 16 && lpe > 16) ? 16 : lpe); }
+__host__ __device__ constexpr int cte_sampler_groups(int N, int lpe) { return 64 / cte_sampler_lanes(N, lpe); }
+// one round of a sampler wave: the first 64 / LS envs of `todo` (bit i = env 64 sw + i needs a placement), one per group of LS
+// lanes; s0..s2 / sF: stream words and free-cell count of env 64 sw + lane, fetched by the caller
+template <int LS>
+__device__ __forceinline__ void cte_sampler_round(const Params &p, int16_t *sscr, int lane, int sw, uint64_t todo, uint4 s0, uint4 s1,
+                                                  uint4 s2, int sF) {
+    constexpr int GS = 64 / LS;
+    const int grp = lane / LS, a = lane % LS;
+    int pick = -1;
+    uint64_t m = todo;
+    for (int g = 0; g < GS; g++) {
+        const int j = m ? (int)__builtin_ctzll(m) : -1;
+        if (m) m &= m - 1;
+        if (g == grp) pick = j;
+    }
+    const bool on = pick >= 0;
+    const int env_s = on ? sw * 64 + pick : 0;
+    // the picked env's stream sits in lane `pick` of the wave: hand it to lane 0 of the group that draws it
+    CtePre spre{true, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+    {
+        const int src = on ? pick : 0;
+        spre.w0 = make_uint4(__shfl(s0.x, src), __shfl(s0.y, src), __shfl(s0.z, src), __shfl(s0.w, src));
+        spre.w1 = make_uint4(__shfl(s1.x, src), __shfl(s1.y, src), __shfl(s1.z, src), __shfl(s1.w, src));
+        spre.w2 = make_uint4(__shfl(s2.x, src), __shfl(s2.y, src), __shfl(s2.z, src), __shfl(s2.w, src));
+        spre.F = __shfl(sF, src);
+    }
+    if (on && a == 0) {  // the visible stream of an env whose placement is pending: the state before this draw
+        uint4 *vw = reinterpret_cast<uint4 *>(p.vis_rng + (size_t)env_s * 6);
+        vw[0] = spre.w0;
+        vw[1] = spre.w1;
+        vw[2] = spre.w2;
+    }
+    Lane drawn;
+    drawn.start = drawn.goal = 0u;
+    cte_sample_starts_goals<LS>(p, p.N, sscr, grp, a, env_s, on, on && a < p.N, drawn, spre);
+    if (on && a < p.N) p.next_sg[(size_t)env_s * p.N + a] = (drawn.start & 0xFFFFu) | (drawn.goal << 16);
+}
+
 struct CteMany {
     int T;         // steps in this launch (1 = mapf_cte_step)
     int obs_mode;  // fused launches: 0 no observation, 1 after the last step only, 2 every step ([T][B][row])
@@ -5705,7 +5745,6 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
         // last step left: somebody further than one move from its goal, step limit not due) gets one drawn here, beside the
         // launch instead of inside its own workgroup's step: nobody else reads or writes its stream or slot in this launch.
         const int sw = (int)blockIdx.x * 2 + wv;
-        int16_t *sscr = wv == 0 ? scratch : reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch2_off);
         const int e = sw * 64 + lane;
         bool need = false;
         // (the env's stream and free-cell count come with the same round trip, speculatively: 52 bytes per env and launch)
@@ -5722,39 +5761,16 @@ __global__ __launch_bounds__(128) void k_cte_step(const Params *__restrict__ pp,
             need = w0 == kSlotInvalid && hint == 0;
         }
         uint64_t todo = __ballot(need);
-        // ONE round per launch -- G envs, one per lane group; the others wait for the next launch: a round (~5 k cycles) ends
-        // well inside the step beside it, a wave that drew all 64 of its envs in the launch after they were re-placed together
-        // (episodes in phase) was the launch's last by 8 rounds (5.24 us per step in phase against 4.98; one round: below)
+        // ONE round per launch -- one env per lane group; the others wait for the next launch: a round (~5 k cycles) ends well
+        // inside the step beside it, a wave that drew all 64 of its envs in the launch after they were re-placed together
+        // (episodes in phase) was the launch's last by 8 rounds (5.24 us per step in phase against 4.98).  The groups of a
+        // sampler wave are as NARROW as the agent count allows, whatever width the step's own groups have (those follow the
+        // H x W observation row): at 32 lanes per env a round of two envs left a wave 32 launches behind a common reset.
         if (todo) {
-            int pick = -1;
-            uint64_t m = todo;
-            for (int g = 0; g < G; g++) {
-                const int j = m ? (int)__builtin_ctzll(m) : -1;
-                if (m) m &= m - 1;
-                if (g == grp) pick = j;
-            }
-            todo = m;
-            const bool on = pick >= 0;
-            const int env_s = on ? sw * 64 + pick : 0;
-            // the picked env's stream sits in lane `pick` of the wave: hand it to lane 0 of the group that draws it
-            CtePre spre{true, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
-            {
-                const int src = on ? pick : 0;
-                spre.w0 = make_uint4(__shfl(s0.x, src), __shfl(s0.y, src), __shfl(s0.z, src), __shfl(s0.w, src));
-                spre.w1 = make_uint4(__shfl(s1.x, src), __shfl(s1.y, src), __shfl(s1.z, src), __shfl(s1.w, src));
-                spre.w2 = make_uint4(__shfl(s2.x, src), __shfl(s2.y, src), __shfl(s2.z, src), __shfl(s2.w, src));
-                spre.F = __shfl(sF, src);
-            }
-            if (on && a == 0) {  // the visible stream of an env whose placement is pending: the state before this draw
-                uint4 *vw = reinterpret_cast<uint4 *>(p.vis_rng + (size_t)env_s * 6);
-                vw[0] = spre.w0;
-                vw[1] = spre.w1;
-                vw[2] = spre.w2;
-            }
-            Lane drawn;
-            drawn.start = drawn.goal = 0u;
-            cte_sample_starts_goals<LPE>(p, p.N, sscr, grp, a, env_s, on, on && a < p.N, drawn, spre);
-            if (on && a < p.N) p.next_sg[(size_t)env_s * p.N + a] = (drawn.start & 0xFFFFu) | (drawn.goal << 16);
+            int16_t *sscr = reinterpret_cast<int16_t *>(lds_raw + io.lds_scratch2_off) + wv * cte_sampler_groups(p.N, LPE) * p.scratch_i16;
+            if (cte_sampler_lanes(p.N, LPE) == 8) cte_sampler_round<8>(p, sscr, lane, sw, todo, s0, s1, s2, sF);
+            else if (cte_sampler_lanes(p.N, LPE) == 16) cte_sampler_round<16>(p, sscr, lane, sw, todo, s0, s1, s2, sF);
+            else cte_sampler_round<LPE>(p, sscr, lane, sw, todo, s0, s1, s2, sF);
         }
         return;
     }

@@ -800,9 +800,10 @@ int mapf_create(const mapf_config *cfg, mapf_handle *out) {
     p.lds_stage_off = rows_bytes + tab_bytes;
     p.lds_scratch_off = rows_bytes + tab_bytes + stage_bytes;
     e->lds_bytes = rows_bytes + tab_bytes + stage_bytes + scratch_bytes;
-    if (cte) {  // a second draw scratch: both waves of a sampler workgroup of k_cte_step draw (CteIo::lds_scratch2_off)
+    if (cte) {  // the draw scratch of the two waves of a sampler workgroup of k_cte_step (CteIo::lds_scratch2_off): their lane
+                // groups are as narrow as the agent count allows (cte_sampler_lanes)
         e->cte_scratch2_off = e->lds_bytes;
-        e->lds_bytes += scratch_bytes;
+        e->lds_bytes += ((2 * cte_sampler_groups(N, lpe) * scratch_i16_alloc * 2) + 15) & ~15;
     }
     {   // wide groups (N > 16): per-env cell map in LDS instead of the all-pairs walk, when it fits and the lock
         // neighbourhood stays inside the map's border
