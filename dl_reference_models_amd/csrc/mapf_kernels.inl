@@ -3634,14 +3634,6 @@ __device__ __forceinline__ void state3_outputs(const Params &p, const Io &io, co
     if (!dec.slow_reset) store_lane_hot(io.agents + idx0, (size_t)lane, img, agent_pass_bits(myrows, img.pos, io.col_pad, io.W));
 }
 
-__device__ __forceinline__ void pin_mask(const WMask<32> &m) { asm volatile("" ::"v"(m.lo)); }
-__device__ __forceinline__ void pin_mask(const WMask<64> &m) { asm volatile("" ::"v"(m.lo)); }
-__device__ __forceinline__ void pin_mask(const WMask<128> &m) { asm volatile("" ::"v"(m.lo), "v"(m.hi)); }
-template <int MW>
-__device__ __forceinline__ void pin_cand(const ObsCand<MW> &c) {
-    pin_mask(c.obst); pin_mask(c.gls); pin_mask(c.occ); pin_mask(c.own);
-    asm volatile("" ::"v"(c.gd_r), "v"(c.gd_c));
-}
 template <int MW>
 __device__ __forceinline__ void window_toggle(WMask<MW> &m, bool on, uint32_t cell, int r0, int c0, int V) {
     const int r = (int)((cell >> 8) & 255u) - r0, c = (int)(cell & 255u) - c0;
@@ -3653,7 +3645,6 @@ __device__ __forceinline__ void obs3_wave_prepared(const Params &p, const Io &io
                                                    const int step_count_in, float *gd_lut) {
     constexpr int G = 64 / LPE;
     constexpr int MAXV = MW == 32 ? 5 : (MW == 64 ? 7 : 11);
-    using gm_t = typename GMask<LPE>::type;
     const int grp = lane / LPE, a = lane % LPE;
     const int N = K::N(p), H = io.H, V = K::V(p), sr = K::sr(p);
     const int RS = H + 2 * kRowPad;
