@@ -28,6 +28,8 @@ class VecSingleAgentReferenceModel:
         self.device = torch.device(cfg.get("device", "cuda:0"))
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        self._dev_index = int(self.device.index)
+        self._out_ptrs = None
         self.num_envs = B = int(cfg.get("num_envs", 1))
         self.num_agents = N = int(cfg.get("num_agents", 2))
         self.steps_per_episode = int(cfg.get("steps_per_episode", 100))
@@ -114,13 +116,22 @@ class VecSingleAgentReferenceModel:
             actions = actions.to(device=self.device, dtype=torch.int8).contiguous()
         if tuple(actions.shape) != (self.num_envs, self.num_agents):
             raise ValueError(f"actions must have shape {(self.num_envs, self.num_agents)}")
-        fo = C.c_void_p(self._final_obs.data_ptr()) if (want_final_obs and auto_reset) else None
-        self._check(self._lib.mapf_cte_step(
-            self._h, C.c_void_p(actions.data_ptr()), C.c_void_p(self._obs.data_ptr()), C.c_void_p(self._reward.data_ptr()),
-            C.c_void_p(self._terminated.data_ptr()), C.c_void_p(self._truncated.data_ptr()),
-            C.c_void_p(self._info.data_ptr()), fo, 1 if auto_reset else 0, self._stream()))
-        return {"obs": self._obs, "reward": self._reward, "terminated": self._terminated, "truncated": self._truncated,
-                "info": self._info, "final_obs": self._final_obs if fo is not None else None}
+        # (the output tensors live as long as the handle: their pointers are marshalled once, the per-call cost is the
+        #  actions' pointer, the raw handle of the current stream and one ctypes call)
+        po = self._out_ptrs
+        if po is None:
+            po = self._out_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._reward, self._terminated, self._truncated,
+                                                                          self._info, self._final_obs))
+            self._out_plain = {"obs": self._obs, "reward": self._reward, "terminated": self._terminated, "truncated": self._truncated,
+                               "info": self._info, "final_obs": None}
+            self._out_final = dict(self._out_plain, final_obs=self._final_obs)
+            self._act_shape = (self.num_envs, self.num_agents)
+        final = want_final_obs and auto_reset
+        rc = self._lib.mapf_cte_step(self._h, actions.data_ptr(), po[0], po[1], po[2], po[3], po[4], po[5] if final else None,
+                                     1 if auto_reset else 0, _raw_stream(self._dev_index))
+        if rc != 0:
+            self._check(rc)
+        return self._out_final if final else self._out_plain
 
     def step_many(self, actions: torch.Tensor, obs_mode: int = 1) -> dict:
         """T fused steps in one launch (mapf_cte_step_many).  actions: int8 [T, B, N].  Returns fresh tensors: obs
