@@ -5216,40 +5216,9 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
     const WideEnd dec = wide_decide<K>(p, io, N, on_goal, is_agent, errored, step0 + 1, nsg);
     const uint64_t irow = l.intent[wide_row(is_agent ? cur : 0u)];
     const bool blocking = is_agent && reached && !moved && ((irow >> (cur & 63u)) & 1ull) != 0;
-    if (!errored) {
-        // +1 each when all stand on their goals, -1 at the step limit for an agent off its goal (finite mode), MA-env:668-690
-        const float term_reward = !(dec.term | dec.trunc) ? 0.0f : (!dec.trunc ? 1.0f : ((lifelong || on_goal) ? 0.0f : -1.0f));
-        const float reward = (grs ? 0.5f : 0.0f) + term_reward;
-        if (is_agent) {
-            if (io.rewards) io.rewards[idx0 + a] = reward;
-            if (io.info_agent) {
-                uchar2 ia;
-                ia.x = blocking ? 1 : 0;
-                ia.y = grs ? 1 : 0;
-                reinterpret_cast<uchar2 *>(io.info_agent)[idx0 + a] = ia;
-            }
-        }
-        if (a == 0) {
-            if (io.terminated) io.terminated[env] = (uint8_t)dec.term;
-            if (io.truncated) io.truncated[env] = (uint8_t)dec.trunc;
-        }
-    }
-    Lane img;
-    img.pos = cur;
-    img.goal = goal;
-    img.start = start;
-    img.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) |
-                ((errored ? pressure_prev : blocking) ? kFlagPressure : 0);
-    img.moved = img.failed = img.progress = 0ull;
-    img.dist = make_uint4(0, 0, 0, 0);
-    if (__builtin_expect(dec.fast_reset, 0)) {  // re-placed from the slot / the fixed starts: the image reset() leaves (MA-env:440-455)
-        const uint32_t rs = deterministic ? (start | (goal << 16)) : nsg;
-        img.start = rs & 0xFFFFu;
-        img.goal = rs >> 16;
-        img.pos = img.start;
-        img.flags = 0u;
-        if (!deterministic && is_agent) slots_of(io.scal, io.B)[idx0 + a] = kSlotInvalid;  // consumed
-    }
+    // The inline draw of an env that ends its episode comes FIRST: the observation wave waits for it at B2 (its reset
+    // observation is what the launch then ends with), the per-agent outputs below do not depend on it
+    uint32_t ns_drawn = kIdleCell, ng_drawn = kIdleGoal;
     if (__builtin_expect(dec.slow_reset, 0)) {
         // ---- the env ends its episode without a pre-drawn placement (lifelong: always): draw inline, MA-env:267-282 ----
         const bool staged = !lifelong && __ballot(is_agent && a == 0 && slot_word_staged(nsg)) != 0;
@@ -5311,9 +5280,47 @@ __global__ __launch_bounds__(192, 3) void k_stepw(const Params *__restrict__ pp,
         }
         l.tab[a].z = ns | (ng << 16);
         wg_sync();  // B2
-        img.start = ns;
-        img.goal = ng;
-        img.pos = ns;
+        ns_drawn = ns;
+        ng_drawn = ng;
+    }
+    if (!errored) {
+        // +1 each when all stand on their goals, -1 at the step limit for an agent off its goal (finite mode), MA-env:668-690
+        const float term_reward = !(dec.term | dec.trunc) ? 0.0f : (!dec.trunc ? 1.0f : ((lifelong || on_goal) ? 0.0f : -1.0f));
+        const float reward = (grs ? 0.5f : 0.0f) + term_reward;
+        if (is_agent) {
+            if (io.rewards) io.rewards[idx0 + a] = reward;
+            if (io.info_agent) {
+                uchar2 ia;
+                ia.x = blocking ? 1 : 0;
+                ia.y = grs ? 1 : 0;
+                reinterpret_cast<uchar2 *>(io.info_agent)[idx0 + a] = ia;
+            }
+        }
+        if (a == 0) {
+            if (io.terminated) io.terminated[env] = (uint8_t)dec.term;
+            if (io.truncated) io.truncated[env] = (uint8_t)dec.trunc;
+        }
+    }
+    Lane img;
+    img.pos = cur;
+    img.goal = goal;
+    img.start = start;
+    img.flags = (reached ? kFlagReached : 0) | (completed ? kFlagCompleted : 0) |
+                ((errored ? pressure_prev : blocking) ? kFlagPressure : 0);
+    img.moved = img.failed = img.progress = 0ull;
+    img.dist = make_uint4(0, 0, 0, 0);
+    if (__builtin_expect(dec.fast_reset, 0)) {  // re-placed from the slot / the fixed starts: the image reset() leaves (MA-env:440-455)
+        const uint32_t rs = deterministic ? (start | (goal << 16)) : nsg;
+        img.start = rs & 0xFFFFu;
+        img.goal = rs >> 16;
+        img.pos = img.start;
+        img.flags = 0u;
+        if (!deterministic && is_agent) slots_of(io.scal, io.B)[idx0 + a] = kSlotInvalid;  // consumed
+    }
+    if (__builtin_expect(dec.slow_reset, 0)) {
+        img.start = ns_drawn;
+        img.goal = ng_drawn;
+        img.pos = ns_drawn;
         img.flags = 0u;
     }
     if (is_agent) store_lane_hot(io.agents + idx0, (size_t)a, img, wide_pass_bits(l.freeb, img.pos));
