@@ -10,6 +10,9 @@ A "step" is one mapf_step launch over one batch of envs (c3: 8192 envs x 32x32 x
 over the GPUs with no hot-path collective: `--scaling weak` (default) keeps 8192 envs per GPU, `--scaling
 strong` splits a fixed total (c4: 65 536) over the ranks.  Started without torchrun and with --gpus N > 1 the
 script launches one fresh child process per GPU itself (before it touches a GPU) and relays rank 0's line.
+Timing with N > 1: every rank leaves a barrier + synchronize, starts its clock, launches its K steps, synchronizes and stops
+its clock, then joins the closing barrier; the job's time is the MAXIMUM of the ranks' times (`per_rank_ms_per_step` lists
+them), so the latency of the closing barrier's own collective is in nobody's K steps.
 
 The timed region is what an RL loop sees in steady state: episode phases are STAGGERED (env b starts at step
 b mod steps_per_episode), so about 1 % of the envs finish and are re-placed inside EVERY launch; `value` is
@@ -633,8 +636,14 @@ def worker(args) -> int:
         ev0.record(stream)
         run_launches(launches, pl_t)
         ev1.record(stream)
-        fence()
+        # Closing side of the bracket: this rank's clock stops when ITS K steps are done (synchronize); the closing barrier comes
+        # behind the clock read -- the job's time is the MAXIMUM over the ranks' times (all-reduced below), i.e. the moment the
+        # slowest rank finished after the common start, and the latency of the barrier collective itself (an RCCL all-reduce
+        # behind the launches: tens of microseconds, a fifth of a 20-step window) is not part of anybody's K steps.
+        torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
         # HIP events on the launch stream over the timed region: device time per launch (graph replays leave no
         # host gap).  This is the kernel time of roofline.frac_kernel.
         kernel_ms = ev0.elapsed_time(ev1) / launches
