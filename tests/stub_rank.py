@@ -1,6 +1,6 @@
 """Stand-in for one rank of `bench.py --gpus N` in the CPU tests of the launcher (tests/test_launcher_gloo.py): same
 rendezvous (torchrun variables, gloo), same shard of the workload (global env ids), same timing protocol (barrier, K
-steps, barrier, every rank's time gathered, the job's time = their maximum, rank 0 prints ONE JSON line) -- with the C
+steps, clock read, barrier, every rank's time gathered, the job's time = their maximum, rank 0 prints ONE JSON line) -- with the C
 oracle as the stepper, because the HIP engine needs a GPU.  STUB_DIE_RANK=<r>: that rank exits with status 3 before the
 rendezvous (the launcher must stop the others and fail)."""
 import json
@@ -40,8 +40,8 @@ def main():
     t0 = time.perf_counter()
     for t in range(args.steps):
         st.step(acts[t % 8])
+    elapsed = time.perf_counter() - t0  # (this rank's own K steps; the closing barrier comes behind the clock read, as in bench.py)
     dist.barrier()
-    elapsed = time.perf_counter() - t0
     tt = torch.zeros(world, dtype=torch.float64)
     tt[rank] = elapsed
     dist.all_reduce(tt)
