@@ -644,6 +644,7 @@ def worker(args) -> int:
         elapsed = time.perf_counter() - t0
         if use_dist:
             dist.barrier()
+        elapsed_incl_barrier = time.perf_counter() - t0  # (reported beside it: ms_per_step_incl_closing_barrier)
         # HIP events on the launch stream over the timed region: device time per launch (graph replays leave no
         # host gap).  This is the kernel time of roofline.frac_kernel.
         kernel_ms = ev0.elapsed_time(ev1) / launches
@@ -657,7 +658,8 @@ def worker(args) -> int:
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)  # (every rank's own time; the job's time is their maximum)
             per_rank = [float(x) for x in tt.tolist()]
             elapsed = max(per_rank)
-        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "resets": resets, "per_rank": per_rank}
+        return {"elapsed": elapsed, "kernel_ms": kernel_ms, "resets": resets, "per_rank": per_rank,
+                "elapsed_incl_barrier": elapsed_incl_barrier}
 
     legs = {}
     if args.episodes in ("staggered", "both"):
@@ -789,6 +791,7 @@ def worker(args) -> int:
         result["roofline"]["frac_kernel_synchronised"] = bytes_per_launch / (s["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
     if world > 1:
         result["per_rank_ms_per_step"] = [1e3 * t / args.steps for t in head["per_rank"]]
+        result["ms_per_step_incl_closing_barrier"] = 1e3 * head["elapsed_incl_barrier"] / args.steps  # (rank 0's clock)
         result["config"]["rank0_cpus"] = len(rank_cpus) if rank_cpus else None
     if args.share_gpu:
         result["shared_gpu"] = True
